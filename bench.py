@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Headline benchmark: paged-attention decode + greedy sampling on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Workload (BASELINE.json `metric`): block_size=16, batch=256 sequences per GPU,
+context 2048 tokens each, 8 query heads = 8 kv heads, head_dim 64, bf16 KV cache
+laid out [blocks, heads, 16, 64] with a fully scattered (random permutation)
+block table; synthetic random data, all inputs resident in HBM before timing.
+
+One step = one decode step of one attention layer for the whole batch:
+  (1) write the new token's K/V rows into their slots   (mi355_kv_write_slots)
+  (2) paged decode attention over the 2048-token context (mi355_paged_decode)
+  (3) greedy sampling from fp32 logits [256, 32000]      (mi355_sample_argmax)
+  (4) with N > 1: all-gather of the sampled ids across ranks (RCCL)
+`value` = sequences (= tokens) decoded per second over all ranks.  `roofline`
+prices step (2), the dominant kernel, against HBM bandwidth using the
+algorithmic byte count; `cpu_baseline` times the reference-shaped CPU decode
+(oracle/loop_form.py) on a bounded sample of the same sequences.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'vllm-from-scratch_amd'))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (guides: 8 TB/s; ~6.3 TB/s measured copy)
+
+CONFIGS = {
+    # BASELINE.json metric config
+    'metric': dict(B=256, S=2048, H=8, D=64, BS=16, vocab=32000),
+    # BASELINE.json configs[1]
+    'c2': dict(B=64, S=1024, H=8, D=64, BS=16, vocab=32000),
+}
+
+
+def algorithmic_bytes(B, S, Hq, Hkv, D, BS, esize):
+    """Bytes one decode launch must move: K and V rows, q and out, block table, context lens."""
+    nblk = (S + BS - 1) // BS
+    return B * S * Hkv * D * 2 * esize + 2 * B * Hq * D * esize + 4 * B * nblk + 4 * B
+
+
+def build_inputs(cfg, device, seed, sets=2):
+    """`sets` independent KV pools that the steps rotate through, so no step finds its
+    working set in the 256 MiB Infinity Cache left by the previous one."""
+    B, S, H, D, BS = cfg['B'], cfg['S'], cfg['H'], cfg['D'], cfg['BS']
+    g = torch.Generator(device=device).manual_seed(seed)
+    per = S // BS
+    NB = B * per + 64
+    pools = []
+    for _ in range(sets):
+        kc = torch.randn((NB, H, BS, D), generator=g, device=device, dtype=torch.float32).to(torch.bfloat16)
+        vc = torch.randn((NB, H, BS, D), generator=g, device=device, dtype=torch.float32).to(torch.bfloat16)
+        bt = torch.randperm(NB, generator=g, device=device)[:B * per].view(B, per).to(torch.int32).contiguous()
+        pools.append((kc, vc, bt))
+    q = torch.randn((B, H, D), generator=g, device=device, dtype=torch.float32).to(torch.bfloat16)
+    k_new = torch.randn((B, H, D), generator=g, device=device, dtype=torch.float32).to(torch.bfloat16)
+    v_new = torch.randn((B, H, D), generator=g, device=device, dtype=torch.float32).to(torch.bfloat16)
+    ctx = torch.full((B,), S, dtype=torch.int32, device=device)
+    logits = torch.randn((B, cfg['vocab']), generator=g, device=device, dtype=torch.float32)
+    # slot of the newest token (position S-1) of every sequence, per pool
+    slots = [(bt[:, (S - 1) // BS].to(torch.int64) * BS + (S - 1) % BS).contiguous() for _, _, bt in pools]
+    return dict(pools=pools, q=q, k_new=k_new, v_new=v_new, ctx=ctx, logits=logits, slots=slots)
+
+
+def cpu_baseline(cfg, inp, budget_s=12.0, max_seqs=32):
+    """Reference-shaped CPU decode on a sample of the benchmark's own sequences (fp32, as the
+    reference runs it).  Returns the JSON object for the bench line."""
+    from oracle import loop_form, paged_oracle
+    B, S, H, D, BS = cfg['B'], cfg['S'], cfg['H'], cfg['D'], cfg['BS']
+    kc, vc, bt = inp['pools'][0]
+    per = S // BS
+    n = min(max_seqs, B)
+    blocks = bt[:n].reshape(-1).long()
+    kv = torch.stack([kc[blocks], vc[blocks]]).float().cpu()          # compact pool [2, n*per, H, BS, D]
+    tables = torch.arange(n * per).view(n, per).tolist()
+    q = inp['q'][:n].float().cpu()
+    threads = torch.get_num_threads()
+    done, t0 = 0, time.perf_counter()
+    while done < n:
+        loop_form.decode_one_sequence(q[done], kv, tables[done], S, BS)
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    # vectorised numpy restatement, for scale
+    kvn = kv.numpy()
+    v0 = time.perf_counter()
+    nv = min(4, n)
+    for i in range(nv):
+        paged_oracle.paged_decode(q[i].numpy(), kvn[0], kvn[1], tables[i], S, BS)
+    vdt = (time.perf_counter() - v0) / nv
+    return {"value": round(done / dt, 3), "unit": "tokens/s", "cores": threads, "kind": "port",
+            "sample": f"{done} of {B} sequences (ctx {S}, {H} heads, d {D}, fp32) through "
+                      f"oracle/loop_form.py, {dt:.1f} s",
+            "ms_per_sequence": round(1e3 * dt / done, 2),
+            "vectorised_numpy_ms_per_sequence": round(1e3 * vdt, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--config', default='metric', choices=sorted(CONFIGS))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"bench.py --gpus {args.gpus}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device")
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group('nccl', device_id=device)
+
+    from mi355_paged import dp, ops
+    cfg = CONFIGS[args.config]
+    B, S, H, D, BS = cfg['B'], cfg['S'], cfg['H'], cfg['D'], cfg['BS']
+    inp = build_inputs(cfg, device, seed=rank)
+    nsets = len(inp['pools'])
+    out = torch.empty((B, H, D), dtype=torch.bfloat16, device=device)
+    ids = torch.empty((B,), dtype=torch.int32, device=device)
+
+    ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+    def step(i, timed):
+        kc, vc, bt = inp['pools'][i % nsets]
+        ops.kv_write_slots(kc, vc, inp['k_new'], inp['v_new'], inp['slots'][i % nsets], 'NHSD')
+        if timed:
+            ev_a[i].record()
+        ops.paged_decode(inp['q'], kc, vc, bt, inp['ctx'], S, layout='NHSD', out=out)
+        if timed:
+            ev_b[i].record()
+        ops.sample_argmax(inp['logits'], out=ids)
+        return dp.all_gather_token_ids(ids, total=B * world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i, False)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        gathered = step(i, True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert gathered.numel() == B * world
+
+    kernel_ms = sorted(a.elapsed_time(b) for a, b in zip(ev_a, ev_b))
+    avg_ms = sum(kernel_ms) / len(kernel_ms)
+    abytes = algorithmic_bytes(B, S, H, H, D, BS, 2)
+    achieved = abytes / (avg_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        line = {
+            "metric": "decode tokens/sec + achieved HBM GB/s, block_size=16 batch=256 seq=2048"
+                      if args.config == 'metric' else f"decode tokens/sec ({args.config})",
+            "value": round(B * world * args.steps / elapsed, 1),
+            "unit": "tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"paged decode step: batch={B}/GPU, ctx={S}, heads={H}, head_dim={D}, "
+                                   f"block_size={BS}, bf16 KV [blocks,heads,{BS},{D}], scattered block table; "
+                                   f"kv-write + paged attention + greedy argmax(vocab={cfg['vocab']})"
+                                   + (" + RCCL all-gather of ids" if world > 1 else ""),
+                       "batch_per_gpu": B, "context": S, "block_size": BS, "parallelism": f"dp{world}"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "mi355_paged_decode (paged_decode_kernel + split merge)",
+                         "algorithmic_bytes_per_launch": abytes,
+                         "avg_launch_ms": round(avg_ms, 5),
+                         "p10_ms": round(kernel_ms[len(kernel_ms) // 10], 5),
+                         "p50_ms": round(kernel_ms[len(kernel_ms) // 2], 5),
+                         "p90_ms": round(kernel_ms[(len(kernel_ms) * 9) // 10], 5)},
+        }
+        traffic_file = os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')
+        if args.config == 'metric' and os.path.exists(traffic_file):
+            with open(traffic_file) as f:
+                line["roofline"]["traffic"] = json.load(f).get("hbm_bytes_per_launch")
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, inp)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,169 @@
+/*
+ * mi355_paged.h -- C ABI of libmi355_paged.so: paged-attention decode, KV slot
+ * write, causal prefill and token sampling as hand-written HIP kernels for
+ * MI355X (gfx950 / CDNA4).
+ *
+ * The reference this library sits under is pure Python; it has no FFI of its
+ * own.  Each entry point below replaces the body of one Python function or
+ * loop of the reference (cited per function, paths relative to the reference
+ * checkout) and is what a binding for that function would call.
+ *
+ * Conventions
+ *  - Every pointer except `stream` and the `const char*` returns is a DEVICE
+ *    pointer owned by the caller (e.g. a torch tensor's data_ptr()).
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *    All work is enqueued on it and the call returns without synchronising.
+ *  - The library allocates no device memory.  Scratch space comes in through
+ *    the `workspace` argument, sized by mi355_paged_decode_workspace_bytes().
+ *  - Strides are in ELEMENTS of the tensor's dtype.  Head rows (the innermost
+ *    D elements) must be contiguous and 16-byte aligned.
+ *  - `dtype`: MI355_F32 = 0, MI355_BF16 = 1, MI355_F16 = 2.  Accumulation is
+ *    always fp32.
+ *  - Return value: 0 on success, a negative MI355_E* code for a rejected
+ *    argument, a positive value = hipError_t from the launch.  A message for
+ *    the last failure on the calling thread is available from
+ *    mi355_last_error().
+ *  - Thread safety: the library keeps no mutable global state besides the
+ *    thread-local error string; calls may be made from any thread.
+ */
+#ifndef MI355_PAGED_H
+#define MI355_PAGED_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_ABI_VERSION 1
+
+#define MI355_F32 0
+#define MI355_BF16 1
+#define MI355_F16 2
+
+#define MI355_OK 0
+#define MI355_EINVAL (-1)      /* bad shape / stride / null pointer            */
+#define MI355_EUNSUPPORTED (-2) /* shape outside the compiled kernel set       */
+#define MI355_EWORKSPACE (-3)   /* workspace missing or too small              */
+
+/* Library ABI version (== MI355_ABI_VERSION the library was built with). */
+int mi355_abi_version(void);
+
+/* Message describing the last non-zero return on this thread ("" if none). */
+const char* mi355_last_error(void);
+
+/*
+ * Paged decode attention for a batch of sequences, one new query token each.
+ * Replaces the body of paged_attention_decode
+ * (01_paged_attention/paged_attention.py:67-101) and the decode branch of
+ * SelfAttention.forward (05_mini_vllm/mini_vllm.py:460-481), batched:
+ *
+ *   for b in [0,B):  for kv_h in [0,Hkv):
+ *     rows i in [0, context_lens[b]) of K and V are fetched from physical block
+ *     block_tables[b][i / block_size], row i % block_size, head kv_h;
+ *     out[b, kv_h*g .. (kv_h+1)*g) = softmax(q . K^T * scale) . V,  g = Hq / Hkv
+ *
+ *   out, q        [B, Hq, D]; q rows may be strided (q_stride_seq elements
+ *                 between sequences; heads are D apart), out is contiguous
+ *   k_cache,
+ *   v_cache       element (block, head, row, d) at
+ *                 block*kv_stride_block + head*kv_stride_head + row*kv_stride_tok + d.
+ *                 [NB,Hkv,BS,D] (reference 01 layout) and [NB,BS,H,D]
+ *                 (reference 05 layout) are both expressible.
+ *   block_tables  [B, max_blocks] int32; only the first
+ *                 ceil(context_lens[b]/block_size) entries of a row are read;
+ *                 ids are clamped to [0, num_blocks)
+ *   context_lens  [B] int32; a row with 0 yields zeros; values are clamped to
+ *                 min(max_context, max_blocks*block_size)
+ *   max_context   host-side upper bound on context_lens (sizes the launch)
+ *   D in {16,32,64,128,256}; Hq % Hkv == 0.
+ *   workspace     >= mi355_paged_decode_workspace_bytes(...) bytes, 16-B aligned
+ *                 (may be NULL when that function returns 0)
+ */
+int mi355_paged_decode(void* out, const void* q, int64_t q_stride_seq,
+                       const void* k_cache, const void* v_cache,
+                       const int32_t* block_tables, const int32_t* context_lens,
+                       int32_t B, int32_t Hq, int32_t Hkv, int32_t D,
+                       int32_t block_size, int32_t max_blocks, int32_t num_blocks,
+                       int32_t max_context,
+                       int64_t kv_stride_block, int64_t kv_stride_head, int64_t kv_stride_tok,
+                       float scale, int32_t dtype,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* Scratch bytes mi355_paged_decode needs for this shape (split-KV partials). */
+size_t mi355_paged_decode_workspace_bytes(int32_t B, int32_t Hq, int32_t Hkv, int32_t D,
+                                          int32_t block_size, int32_t max_context, int32_t dtype);
+
+/*
+ * Scatter T new K/V rows into the paged caches by flat slot id
+ * (slot = block*block_size + row).  Replaces the per-token write loops
+ * 01_paged_attention/paged_attention.py:118-123, KVCachePool.write_kv (:48-51)
+ * and the indexed assignment 05_mini_vllm/mini_vllm.py:421-427.
+ *   k, v   [T, Hkv, D] with src_stride_tok elements between tokens
+ *   slots  [T] int64; a negative slot or one >= num_blocks*block_size is skipped
+ */
+int mi355_kv_write_slots(void* k_cache, void* v_cache, const void* k, const void* v,
+                         const int64_t* slots, int32_t T, int32_t Hkv, int32_t D,
+                         int64_t src_stride_tok, int32_t block_size, int32_t num_blocks,
+                         int64_t kv_stride_block, int64_t kv_stride_head, int64_t kv_stride_tok,
+                         int32_t dtype, void* stream);
+
+/*
+ * Causal self-attention over packed variable-length sequences (prompt
+ * processing).  Replaces 01_paged_attention/paged_attention.py:125-136 and the
+ * prefill branch 05_mini_vllm/mini_vllm.py:437-458.
+ *   q [T, Hq, D], k/v [T, Hkv, D] (token strides given), out [T, Hq, D] contiguous
+ *   cu_seqlens [nseq+1] int32: sequence i owns tokens cu_seqlens[i]..cu_seqlens[i+1]-1,
+ *               cu_seqlens[0] = 0, cu_seqlens[nseq] = total_tokens
+ *   total_tokens T (host copy of cu_seqlens[nseq]); max_seqlen: host-side upper
+ *               bound on any sequence length
+ */
+int mi355_prefill_causal(void* out, const void* q, const void* k, const void* v,
+                         int64_t q_stride_tok, int64_t kv_stride_tok,
+                         const int32_t* cu_seqlens, int32_t nseq, int32_t total_tokens,
+                         int32_t max_seqlen, int32_t Hq, int32_t Hkv, int32_t D, float scale,
+                         int32_t dtype, void* stream);
+
+/*
+ * Greedy sampling: out_ids[b] = argmax(logits[b, :vocab]).  Replaces
+ * 05_mini_vllm/mini_vllm.py:611-613 (torch.argmax per request + .item()).
+ * Ties give the lowest index; NaN counts as the maximum (first NaN wins),
+ * matching torch.argmax.  logits rows are row_stride elements apart.
+ */
+int mi355_sample_argmax(int32_t* out_ids, const void* logits, int32_t B, int32_t vocab,
+                        int64_t row_stride, int32_t dtype, void* stream);
+
+/*
+ * Stochastic sampling: temperature -> softmax -> optional top-k -> optional
+ * top-p (nucleus) -> one multinomial draw per row.  Replaces
+ * 05_mini_vllm/mini_vllm.py:615-630.  Nucleus rule as in the reference: with
+ * tokens ranked by descending probability, a token is dropped when the mass
+ * ranked strictly before it is >= top_p (the top token always survives).
+ *   temperature [B] float (> 0), top_p [B] float or NULL (= 1.0),
+ *   top_k [B] int32 or NULL (<= 0 = off; not in the reference, additive)
+ *   seed/offset select the counter-based random stream: row b draws from
+ *   philox(seed, offset + b).
+ *   out_probs: optional [B, vocab] float; when non-NULL receives the
+ *   renormalised post-filter distribution (for tests / inspection).
+ */
+int mi355_sample_topk_topp(int32_t* out_ids, const void* logits, const float* temperature,
+                           const float* top_p, const int32_t* top_k, uint64_t seed,
+                           uint64_t offset, int32_t B, int32_t vocab, int64_t row_stride,
+                           int32_t dtype, float* out_probs, void* stream);
+
+/*
+ * Batched slot mapping on the device: for sequence b and i in [0, counts[b]):
+ *   out_slots[cu_tokens[b] + i] =
+ *       block_tables[b][(starts[b]+i) / block_size] * block_size + (starts[b]+i) % block_size
+ * Replaces compute_slot_mapping (01_paged_attention/paged_attention.py:54-64)
+ * and Scheduler._compute_slot_mapping (05_mini_vllm/mini_vllm.py:209-219).
+ */
+int mi355_slot_mapping(int64_t* out_slots, const int32_t* block_tables, const int32_t* starts,
+                       const int32_t* cu_tokens, int32_t B, int32_t max_blocks,
+                       int32_t block_size, int32_t total_tokens, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_PAGED_H */

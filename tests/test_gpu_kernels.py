@@ -1,0 +1,344 @@
+"""HIP kernels vs the CPU oracle and the golden vectors (needs an MI355X).
+
+Every call goes through the C ABI (ctypes binding in mi355_paged/_lib.py).
+Tolerances:
+  fp32 kernels:  atol=1e-5, rtol=1e-5 against the fp32 golden outputs (the reference's own bar,
+                 01_paged_attention/test_paged_attention.py:99);
+  bf16 / fp16:   oracle = float64 attention on the rounded inputs; the kernel accumulates in
+                 fp32 and rounds once on store -> atol=1e-2, rtol=1.6e-2 (two bf16 ulps);
+  indices, slot writes, greedy ids: bit-exact.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_json, load_npz, npz_cases
+from oracle import paged_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+LOWP_TOL = dict(atol=1e-2, rtol=1.6e-2)
+F32_TOL = dict(atol=1e-5, rtol=1e-5)
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from mi355_paged import ops as _ops
+    return _ops
+
+
+def _decode_on_gpu(ops, device, q, cache, block_tables, ctx, dtype, layout='NHSD'):
+    """q [B,Hq,D], cache [2,NB,Hkv,BS,D] float32 numpy -> numpy float32 result."""
+    tq = torch.from_numpy(q).to(device=device, dtype=dtype)
+    tc = torch.from_numpy(cache).to(device=device, dtype=dtype)
+    if layout == 'NSHD':
+        tc = tc.permute(0, 1, 3, 2, 4).contiguous()
+    bt = torch.from_numpy(np.asarray(block_tables, dtype=np.int32)).to(device)
+    cl = torch.tensor(ctx, dtype=torch.int32, device=device)
+    out = ops.paged_decode(tq, tc[0], tc[1], bt, cl, max(ctx) if len(ctx) else 0, layout=layout)
+    torch.cuda.synchronize()
+    return out.float().cpu().numpy()
+
+
+def test_g1_known_answer_fp32(ops, device):
+    z = load_npz('g1_decode_known_answer.npz')
+    out = _decode_on_gpu(ops, device, z['query'][None], z['kv_cache'], [z['block_table'].tolist()],
+                         [int(z['seq_len'])], torch.float32)[0]
+    np.testing.assert_allclose(out, z['out_paged'], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(out, z['out_dense'], atol=1e-5, rtol=0)
+
+
+@pytest.mark.parametrize('layout', ['NHSD', 'NSHD'])
+@pytest.mark.parametrize('case', npz_cases('g2_decode_cases.npz'), ids=lambda c: str(c[0]))
+def test_g2_decode_cases_fp32(ops, device, case, layout):
+    m, f = case
+    out = _decode_on_gpu(ops, device, f['query'].astype(np.float32)[None], f['kv_cache'].astype(np.float32),
+                         [f['block_table'].tolist()], [m['s']], torch.float32, layout)[0]
+    np.testing.assert_allclose(out, f['out'], **F32_TOL)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('case', npz_cases('g2_decode_cases.npz'), ids=lambda c: str(c[0]))
+def test_g2_decode_cases_lowp(ops, device, case, dtype):
+    m, f = case
+    q = torch.from_numpy(f['query'].astype(np.float32)).to(dtype).float().numpy()
+    cache = torch.from_numpy(f['kv_cache'].astype(np.float32)).to(dtype).float().numpy()
+    want = orc.paged_decode(q, cache[0], cache[1], f['block_table'].tolist(), m['s'], m['bs'], dtype=np.float64)
+    out = _decode_on_gpu(ops, device, q[None], cache, [f['block_table'].tolist()], [m['s']], dtype)[0]
+    np.testing.assert_allclose(out, want, **LOWP_TOL)
+
+
+def _random_batch(rng, B, Hq, Hkv, D, BS, max_ctx, ragged=True, spare=7):
+    ctx = rng.integers(1, max_ctx + 1, size=B) if ragged else np.full(B, max_ctx)
+    per = (max_ctx + BS - 1) // BS
+    NB = B * per + spare
+    perm = rng.permutation(NB)[:B * per].reshape(B, per).astype(np.int32)
+    cache = rng.standard_normal((2, NB, Hkv, BS, D), dtype=np.float32)
+    q = rng.standard_normal((B, Hq, D), dtype=np.float32)
+    return q, cache, perm, [int(c) for c in ctx]
+
+
+@pytest.mark.parametrize('shape', [
+    # B, Hq, Hkv, D, BS, max_ctx
+    (5, 8, 8, 64, 16, 300), (3, 8, 4, 64, 16, 700), (4, 8, 2, 32, 8, 130), (2, 8, 1, 128, 16, 257),
+    (3, 12, 4, 64, 16, 90), (2, 16, 1, 64, 16, 70), (3, 4, 4, 16, 4, 50), (2, 6, 6, 256, 16, 40),
+    (7, 8, 8, 64, 3, 100), (1, 8, 8, 64, 16, 5000),
+])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_decode_batched_ragged(ops, device, shape, dtype):
+    """Ragged batches, GQA groupings, odd block sizes and long contexts (split-KV path)."""
+    B, Hq, Hkv, D, BS, max_ctx = shape
+    rng = np.random.default_rng(hash(shape) % (2 ** 31))
+    q, cache, bt, ctx = _random_batch(rng, B, Hq, Hkv, D, BS, max_ctx)
+    if dtype != torch.float32:
+        q = torch.from_numpy(q).to(dtype).float().numpy()
+        cache = torch.from_numpy(cache).to(dtype).float().numpy()
+    want = orc.paged_decode_batch(q, cache[0], cache[1], bt, ctx, BS, dtype=np.float64)
+    out = _decode_on_gpu(ops, device, q, cache, bt, ctx, dtype)
+    np.testing.assert_allclose(out, want, **(F32_TOL if dtype == torch.float32 else LOWP_TOL))
+
+
+def test_decode_zero_context_rows(ops, device):
+    rng = np.random.default_rng(5)
+    q, cache, bt, ctx = _random_batch(rng, 4, 8, 8, 64, 16, 64)
+    ctx[1] = 0
+    ctx[3] = 0
+    out = _decode_on_gpu(ops, device, q, cache, bt, ctx, torch.float32)
+    want = orc.paged_decode_batch(q, cache[0], cache[1], bt, ctx, 16)
+    np.testing.assert_allclose(out, want, **F32_TOL)
+    assert not out[1].any() and not out[3].any()
+
+
+def test_decode_softmax_spike(ops, device):
+    """A late key that dominates every earlier one forces the running-max rescale path."""
+    rng = np.random.default_rng(11)
+    q, cache, bt, ctx = _random_batch(rng, 2, 8, 8, 64, 16, 600, ragged=False)
+    for b in range(2):
+        pos = 500 + b
+        blk, row = bt[b][pos // 16], pos % 16
+        cache[0, blk, :, row, :] = q[b] * 4.0     # score ~ 4*|q|^2/8 >> the rest
+    want = orc.paged_decode_batch(q, cache[0], cache[1], bt, ctx, 16, dtype=np.float64)
+    out = _decode_on_gpu(ops, device, q, cache, bt, ctx, torch.float32)
+    np.testing.assert_allclose(out, want, atol=2e-5, rtol=1e-4)
+
+
+def test_decode_metric_shape_subset_bf16(ops, device):
+    """The benchmark configuration (B=256, S=2048, 8 heads, D=64, BS=16, bf16), checked on a
+    random subset of sequences against the float64 oracle, plus two size-independent
+    properties: rows are independent of batch position and of physical block placement."""
+    B, S, H, D, BS = 256, 2048, 8, 64, 16
+    g = torch.Generator(device='cpu').manual_seed(0)
+    NB = B * S // BS + S // BS
+    kc = torch.randn((NB, H, BS, D), generator=g, dtype=torch.float32).to(torch.bfloat16)
+    vc = torch.randn((NB, H, BS, D), generator=g, dtype=torch.float32).to(torch.bfloat16)
+    q = torch.randn((B, H, D), generator=g, dtype=torch.float32).to(torch.bfloat16)
+    bt = torch.randperm(NB, generator=g)[:B * S // BS].view(B, S // BS).to(torch.int32)
+    ctx = torch.full((B,), S, dtype=torch.int32)
+    out = ops.paged_decode(q.to(device), kc.to(device), vc.to(device), bt.to(device), ctx.to(device), S)
+    torch.cuda.synchronize()
+    out = out.float().cpu().numpy()
+    kcf, vcf = kc.float().numpy(), vc.float().numpy()
+    for b in (0, 17, 101, 255):
+        want = orc.paged_decode(q[b].float().numpy(), kcf, vcf, bt[b].tolist(), S, BS, dtype=np.float64)
+        np.testing.assert_allclose(out[b], want, **LOWP_TOL)
+    # property 1: a reversed batch gives reversed rows, bit for bit
+    rev = torch.arange(B - 1, -1, -1)
+    out_rev = ops.paged_decode(q[rev].to(device), kc.to(device), vc.to(device), bt[rev].to(device),
+                               ctx.to(device), S)
+    assert torch.equal(out_rev.cpu(), torch.from_numpy(out).to(torch.bfloat16)[rev])
+    # property 2: moving a sequence's blocks elsewhere in the pool changes nothing
+    spare = torch.tensor([i for i in range(NB) if i not in set(bt.flatten().tolist())][:S // BS])
+    kc2, vc2, bt2 = kc.clone(), vc.clone(), bt.clone()
+    kc2[spare] = kc[bt[3].long()]
+    vc2[spare] = vc[bt[3].long()]
+    bt2[3] = spare.to(torch.int32)
+    out2 = ops.paged_decode(q[3:4].to(device), kc2.to(device), vc2.to(device), bt2[3:4].to(device),
+                            ctx[3:4].to(device), S)
+    np.testing.assert_allclose(out2.float().cpu().numpy()[0], out[3], **LOWP_TOL)
+
+
+def test_decode_bad_arguments(ops, device):
+    from mi355_paged._lib import Mi355Error
+    q = torch.zeros((1, 8, 48), device=device)
+    kc = torch.zeros((4, 8, 16, 48), device=device)
+    bt = torch.zeros((1, 4), dtype=torch.int32, device=device)
+    cl = torch.ones((1,), dtype=torch.int32, device=device)
+    with pytest.raises(Mi355Error, match='head_dim'):
+        ops.paged_decode(q, kc, kc, bt, cl, 1)
+    with pytest.raises(RuntimeError, match='HIP device'):
+        ops.paged_decode(q.cpu(), kc, kc, bt, cl, 1)
+
+
+# ------------------------------------------------------------------ KV write / prefill
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('layout', ['NHSD', 'NSHD'])
+def test_kv_write_slots_exact(ops, device, dtype, layout):
+    rng = np.random.default_rng(3)
+    NB, H, BS, D, T = 9, 4, 8, 32, 37
+    cache = torch.from_numpy(rng.standard_normal((2, NB, H, BS, D), dtype=np.float32)).to(dtype)
+    k = torch.from_numpy(rng.standard_normal((T, H, D), dtype=np.float32)).to(dtype)
+    v = torch.from_numpy(rng.standard_normal((T, H, D), dtype=np.float32)).to(dtype)
+    slots = rng.permutation(NB * BS)[:T].astype(np.int64)
+    slots[5] = -1                      # padding slot: skipped
+    want = cache.float().numpy().copy()
+    keep = slots >= 0
+    orc.kv_write_slots(want[0], want[1], k.float().numpy()[keep], v.float().numpy()[keep], slots[keep], BS)
+    dc = cache.to(device)
+    if layout == 'NSHD':
+        dc = dc.permute(0, 1, 3, 2, 4).contiguous()
+    ops.kv_write_slots(dc[0], dc[1], k.to(device), v.to(device), torch.from_numpy(slots).to(device), layout)
+    torch.cuda.synchronize()
+    got = dc.permute(0, 1, 3, 2, 4) if layout == 'NSHD' else dc
+    np.testing.assert_array_equal(got.float().cpu().numpy(), want)
+
+
+@pytest.mark.parametrize('case', npz_cases('g3_prefill_cases.npz'), ids=lambda c: str(c[0]))
+def test_g3_prefill_cases_fp32(ops, device, case):
+    import paged_attention as pa
+    m, f = case
+    cache = torch.from_numpy(f['cache_before'].astype(np.float32)).to(device)
+    out = pa.paged_attention_prefill(torch.from_numpy(f['query'].astype(np.float32)).to(device),
+                                     torch.from_numpy(f['key'].astype(np.float32)).to(device),
+                                     torch.from_numpy(f['value'].astype(np.float32)).to(device),
+                                     cache, f['block_table'].tolist(), m['bs'])
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), f['out'], **F32_TOL)
+    np.testing.assert_array_equal(cache.cpu().numpy(), f['cache_after'].astype(np.float32))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_prefill_varlen_packed(ops, device, dtype):
+    rng = np.random.default_rng(8)
+    lens = [1, 17, 64, 130, 5]
+    Hq, Hkv, D = 8, 4, 64
+    T = sum(lens)
+    q = torch.from_numpy(rng.standard_normal((T, Hq, D), dtype=np.float32)).to(dtype)
+    k = torch.from_numpy(rng.standard_normal((T, Hkv, D), dtype=np.float32)).to(dtype)
+    v = torch.from_numpy(rng.standard_normal((T, Hkv, D), dtype=np.float32)).to(dtype)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    want = orc.varlen_causal_attention(q.float().numpy(), k.float().numpy(), v.float().numpy(), cu,
+                                       dtype=np.float64)
+    out = ops.prefill_causal(q.to(device), k.to(device), v.to(device), torch.from_numpy(cu).to(device),
+                             max(lens))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.float().cpu().numpy(), want,
+                               **(F32_TOL if dtype == torch.float32 else LOWP_TOL))
+
+
+def test_slot_mapping_device(ops, device):
+    rng = np.random.default_rng(21)
+    B, max_blocks, BS = 6, 12, 8
+    bt = rng.integers(0, 500, size=(B, max_blocks)).astype(np.int32)
+    starts = rng.integers(0, 40, size=B).astype(np.int32)
+    counts = rng.integers(0, 50, size=B)
+    counts = np.minimum(counts, max_blocks * BS - starts)
+    cu = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    want = []
+    for b in range(B):
+        want += orc.slot_mapping_range(bt[b], int(starts[b]), int(counts[b]), BS)
+    got = ops.slot_mapping(torch.from_numpy(bt).to(device), torch.from_numpy(starts).to(device),
+                           torch.from_numpy(cu[:-1].copy()).to(device), int(cu[-1]), BS)
+    assert got.cpu().tolist() == want
+
+
+# ------------------------------------------------------------------ sampler
+def _row(vals):
+    conv = {None: float('nan'), 'inf': float('inf'), '-inf': float('-inf')}
+    return [conv[v] if (v is None or isinstance(v, str)) else v for v in vals]
+
+
+def test_argmax_golden_rows(ops, device):
+    g = load_json('g7_sampler.json')
+    rows = torch.tensor([_row(r) for r in g['greedy_rows']], dtype=torch.float32, device=device)
+    assert ops.sample_argmax(rows).cpu().tolist() == g['greedy_ids']
+    z = load_npz('g7_sampler_big.npz')
+    got = ops.sample_argmax(torch.from_numpy(z['logits']).to(device)).cpu().tolist()
+    assert got == z['greedy_ids'].tolist()
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('vocab', [1, 3, 1000, 32000, 50257])
+def test_argmax_random_exact(ops, device, dtype, vocab):
+    g = torch.Generator().manual_seed(vocab)
+    logits = torch.randn((33, vocab), generator=g).to(dtype)
+    if vocab >= 1000:
+        logits[4, 777] = float('nan')
+        logits[4, 12] = float('nan')
+        logits[7, :] = 1.5            # all ties -> index 0
+        logits[9, 900] = logits[9].float().max().item() + 1
+        logits[9, 901] = logits[9, 900]
+    want = orc.argmax_rows(logits.float().numpy())
+    assert ops.sample_argmax(logits.to(device)).cpu().tolist() == want
+    sliced = torch.zeros((33, vocab + 5), dtype=dtype)          # strided rows, unaligned
+    sliced[:, 1:vocab + 1] = logits
+    assert ops.sample_argmax(sliced.to(device)[:, 1:vocab + 1]).cpu().tolist() == want
+
+
+def test_nucleus_kept_set_matches_reference(ops, device):
+    cases = load_json('g7_sampler.json')['nucleus']
+    logits = torch.tensor([c['logits'] for c in cases], dtype=torch.float32, device=device)
+    temp = torch.tensor([c['temperature'] for c in cases], device=device)
+    top_p = torch.tensor([c['top_p'] for c in cases], device=device)
+    ids, probs = ops.sample_topk_topp(logits, temp, top_p, None, seed=1, return_probs=True)
+    probs = probs.cpu().numpy()
+    for i, c in enumerate(cases):
+        kept = sorted(np.nonzero(probs[i])[0].tolist())
+        assert kept == sorted(c['kept_ids_sorted'])                                   # exact set
+        np.testing.assert_allclose(probs[i][c['kept_ids_sorted']], c['kept_probs_sorted'],
+                                   rtol=1e-4, atol=1e-6)
+        assert int(ids[i]) in kept
+
+
+@pytest.mark.parametrize('vocab', [50, 1000, 5000, 32000, 70000])
+def test_sampling_filters_match_oracle(ops, device, vocab):
+    rng = np.random.default_rng(vocab)
+    B = 6
+    logits = (rng.standard_normal((B, vocab)) * 3).astype(np.float32)
+    temps = [1.0, 0.7, 1.3, 0.5, 1.0, 2.0]
+    top_ps = [0.9, 0.5, 1.0, 0.95, 1.0, 0.3]
+    top_ks = [0, 0, 40, 10, 0, 5]
+    ids, probs = ops.sample_topk_topp(torch.from_numpy(logits).to(device), torch.tensor(temps, device=device),
+                                      torch.tensor(top_ps, device=device),
+                                      torch.tensor(top_ks, dtype=torch.int32, device=device),
+                                      seed=123, return_probs=True)
+    probs = probs.cpu().numpy()
+    for b in range(B):
+        want, kept = orc.nucleus_probs(logits[b], temps[b], top_ps[b], top_ks[b])
+        got_kept = probs[b] > 0
+        # the kept set may differ by the boundary token when the running mass is within float
+        # rounding of top_p; everywhere else it must be identical
+        diff = np.nonzero(got_kept != kept)[0]
+        assert len(diff) <= 1, f"row {b}: kept sets differ at {diff}"
+        if len(diff) == 0:
+            np.testing.assert_allclose(probs[b], want, rtol=2e-4, atol=1e-7)
+        assert got_kept[int(ids[b])]
+        assert abs(probs[b].sum() - 1.0) < 1e-4
+
+
+def test_sampling_distribution(ops, device):
+    """Draws follow the filtered distribution (chi-square style bound on 20k draws)."""
+    vocab, n = 16, 20000
+    logits = torch.linspace(-2, 2, vocab).repeat(n, 1).to(device)
+    temp = torch.full((n,), 0.8, device=device)
+    top_p = torch.full((n,), 0.9, device=device)
+    ids = ops.sample_topk_topp(logits, temp, top_p, None, seed=7).cpu().numpy()
+    want, _ = orc.nucleus_probs(logits[0].cpu().numpy(), 0.8, 0.9)
+    freq = np.bincount(ids, minlength=vocab) / n
+    assert np.all(freq[want == 0] == 0)
+    assert np.all(np.abs(freq - want) <= 4 * np.sqrt(want * (1 - want) / n) + 1e-3)
+    again = ops.sample_topk_topp(logits, temp, top_p, None, seed=7).cpu().numpy()
+    assert np.array_equal(ids, again)                      # same seed -> same draws
+    other = ops.sample_topk_topp(logits, temp, top_p, None, seed=8).cpu().numpy()
+    assert not np.array_equal(ids, other)
+
+
+def test_sampling_temperature_spread(ops, device):
+    """Mirror of the reference's test_temperature_affects_distribution
+    (05_mini_vllm/test_mini_vllm.py:195-211) on the kernel itself."""
+    torch.manual_seed(42)
+    logits = torch.randn(1, 100).repeat(200, 1).to(device)
+    low = ops.sample_topk_topp(logits, torch.full((200,), 0.1, device=device), None, None, seed=1)
+    high = ops.sample_topk_topp(logits, torch.full((200,), 10.0, device=device), None, None, seed=1)
+    assert len(set(low.cpu().tolist())) < len(set(high.cpu().tolist()))

@@ -1,0 +1,86 @@
+"""The CPU oracle against the golden vectors captured from the reference (CPU only)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_json, load_npz, npz_cases
+from oracle import loop_form, paged_oracle as orc
+
+
+def test_g1_known_answer():
+    z = load_npz('g1_decode_known_answer.npz')
+    cache = z['kv_cache']
+    out = orc.paged_decode(z['query'], cache[0], cache[1], z['block_table'].tolist(),
+                           int(z['seq_len']), int(z['block_size']))
+    # same bar as the reference's own test (01_paged_attention/test_paged_attention.py:99)
+    np.testing.assert_allclose(out, z['out_paged'], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(out, z['out_dense'], atol=1e-5, rtol=0)
+
+
+@pytest.mark.parametrize('case', npz_cases('g2_decode_cases.npz'), ids=lambda c: str(c[0]))
+def test_g2_decode_cases(case):
+    m, f = case
+    cache = f['kv_cache'].astype(np.float32)
+    q = f['query'].astype(np.float32)
+    bt = f['block_table'].tolist()
+    out = orc.paged_decode(q, cache[0], cache[1], bt, m['s'], m['bs'])
+    np.testing.assert_allclose(out, f['out'], atol=1e-5, rtol=1e-5)
+    out64 = orc.paged_decode(q, cache[0], cache[1], bt, m['s'], m['bs'], dtype=np.float64)
+    np.testing.assert_allclose(out64, f['out'], atol=1e-5, rtol=1e-5)
+    loop = loop_form.decode_one_sequence(torch.from_numpy(q), torch.from_numpy(cache), bt, m['s'], m['bs'])
+    np.testing.assert_allclose(loop.numpy(), f['out'], atol=1e-6, rtol=1e-6)
+
+
+@pytest.mark.parametrize('case', npz_cases('g3_prefill_cases.npz'), ids=lambda c: str(c[0]))
+def test_g3_prefill_cases(case):
+    m, f = case
+    cache = f['cache_before'].astype(np.float32).copy()
+    out = orc.paged_prefill(f['query'].astype(np.float32), f['key'].astype(np.float32),
+                            f['value'].astype(np.float32), cache[0], cache[1],
+                            f['block_table'].tolist(), m['bs'])
+    np.testing.assert_allclose(out, f['out'], atol=1e-5, rtol=1e-5)
+    np.testing.assert_array_equal(cache, f['cache_after'].astype(np.float32))   # writes are exact copies
+
+
+def test_g4_slot_mapping():
+    for c in load_json('g4_slot_mapping.json'):
+        assert orc.slot_mapping(c['block_table'], c['seq_len'], c['block_size']) == c['slots']
+        assert orc.slot_mapping_range(c['block_table'], 0, c['seq_len'], c['block_size']) == c['slots']
+
+
+def test_g5_pool_model():
+    g = load_json('g5_allocator_traces.json')['pool']
+    pool = orc.PoolModel(g['num_blocks'])
+    for rec in g['trace']:
+        if rec['op'] == 'alloc':
+            if 'error' in rec:
+                with pytest.raises(RuntimeError, match='OOM'):
+                    pool.allocate(rec['arg'])
+            else:
+                assert pool.allocate(rec['arg']) == rec['result']
+        else:
+            pool.free(rec['arg'])
+        assert pool.free_blocks == rec['free_blocks']
+        assert pool.ref_counts == rec['ref_counts']
+
+
+def _row(vals):
+    conv = {None: float('nan'), 'inf': float('inf'), '-inf': float('-inf')}
+    return [conv[v] if (v is None or isinstance(v, str)) else v for v in vals]
+
+
+def test_g7_greedy():
+    g = load_json('g7_sampler.json')
+    for row, want in zip(g['greedy_rows'], g['greedy_ids']):
+        assert orc.argmax_rows(np.array([_row(row)], dtype=np.float32)) == [want]
+    z = load_npz('g7_sampler_big.npz')
+    assert orc.argmax_rows(z['logits']) == z['greedy_ids'].tolist()
+
+
+def test_g7_nucleus():
+    for c in load_json('g7_sampler.json')['nucleus']:
+        probs, kept = orc.nucleus_probs(np.array(c['logits'], dtype=np.float32), c['temperature'], c['top_p'])
+        ids = c['kept_ids_sorted']
+        assert sorted(np.nonzero(kept)[0].tolist()) == sorted(ids)          # kept set exact
+        np.testing.assert_allclose(probs[ids], c['kept_probs_sorted'], rtol=1e-5, atol=1e-7)
+        assert abs(float(probs.sum()) - 1.0) < 1e-5

@@ -1,0 +1,195 @@
+// Shared device/host helpers for the mi355_paged kernels (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/mi355_paged.h"
+
+namespace mi355 {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+
+constexpr int kWave = 64;
+
+// Records `code` and a printf-style message for mi355_last_error(); returns code.
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+// Returns 0 or records + returns the pending hipError_t of the last launch.
+int check_launch(const char* what);
+
+static inline int ilog2_exact(int v) {  // log2(v) if v is a power of two, else -1
+  if (v <= 0 || (v & (v - 1))) return -1;
+  int s = 0;
+  while ((1 << s) < v) ++s;
+  return s;
+}
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Bit reinterpretation helpers that take their argument BY VALUE.  Applying
+// __builtin_bit_cast directly to an element of an ext_vector lvalue (v[i]) reads
+// element 0 for every i with this compiler; going through a by-value scalar
+// parameter avoids that.
+__device__ __forceinline__ float u2f(uint32_t x) { return __builtin_bit_cast(float, x); }
+__device__ __forceinline__ uint32_t f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ bf16x2_t u2bf2(uint32_t x) { return __builtin_bit_cast(bf16x2_t, x); }
+__device__ __forceinline__ f16x2_t u2h2(uint32_t x) { return __builtin_bit_cast(f16x2_t, x); }
+
+// ---------------------------------------------------------------------------
+// dtype tags.  A lane always moves 16 bytes: kEPL elements.
+// ---------------------------------------------------------------------------
+struct F32 {
+  static constexpr int kBytes = 4, kEPL = 4, kCode = MI355_F32;
+  typedef float elem_t;
+  struct QFrag { float f[4]; };
+  static __device__ __forceinline__ QFrag make_q(u32x4 raw) {
+    QFrag q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q.f[i] = u2f(raw[i]);
+    return q;
+  }
+  static __device__ __forceinline__ float dot(const QFrag& q, u32x4 k) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s = __builtin_fmaf(q.f[i], u2f(k[i]), s);
+    return s;
+  }
+  static __device__ __forceinline__ void unpack(u32x4 raw, float (&f)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = u2f(raw[i]);
+  }
+  static __device__ __forceinline__ u32x4 pack(const float (&f)[4]) {
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = f2u(f[i]);
+    return r;
+  }
+  static __device__ __forceinline__ float to_float(elem_t v) { return v; }
+};
+
+struct BF16 {
+  static constexpr int kBytes = 2, kEPL = 8, kCode = MI355_BF16;
+  typedef uint16_t elem_t;
+  struct QFrag { uint32_t w[4]; };
+  static __device__ __forceinline__ QFrag make_q(u32x4 raw) {
+    QFrag q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q.w[i] = raw[i];
+    return q;
+  }
+  // bf16 x bf16 products are exact in fp32; v_dot2c_f32_bf16 adds two of them
+  // into the fp32 accumulator per instruction.
+  static __device__ __forceinline__ float dot(const QFrag& q, u32x4 k) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      s = __builtin_amdgcn_fdot2_f32_bf16(u2bf2(k[i]), u2bf2(q.w[i]), s, false);
+    return s;
+  }
+  static __device__ __forceinline__ void unpack(u32x4 raw, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = u2f(raw[i] << 16);
+      f[2 * i + 1] = u2f(raw[i] & 0xffff0000u);
+    }
+  }
+  static __device__ __forceinline__ uint32_t round1(float x) {  // RNE, NaN stays NaN
+    __bf16 b = (__bf16)x;
+    return (uint32_t)__builtin_bit_cast(uint16_t, b);
+  }
+  static __device__ __forceinline__ u32x4 pack(const float (&f)[8]) {
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = round1(f[2 * i]) | (round1(f[2 * i + 1]) << 16);
+    return r;
+  }
+  static __device__ __forceinline__ float to_float(elem_t v) {
+    return __builtin_bit_cast(float, (uint32_t)v << 16);
+  }
+};
+
+struct F16 {
+  static constexpr int kBytes = 2, kEPL = 8, kCode = MI355_F16;
+  typedef uint16_t elem_t;
+  struct QFrag { uint32_t w[4]; };
+  static __device__ __forceinline__ QFrag make_q(u32x4 raw) {
+    QFrag q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q.w[i] = raw[i];
+    return q;
+  }
+  static __device__ __forceinline__ float dot(const QFrag& q, u32x4 k) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      s = __builtin_amdgcn_fdot2(u2h2(k[i]), u2h2(q.w[i]), s, false);
+    return s;
+  }
+  static __device__ __forceinline__ void unpack(u32x4 raw, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f16x2_t h = u2h2(raw[i]);
+      f[2 * i] = (float)h[0];
+      f[2 * i + 1] = (float)h[1];
+    }
+  }
+  static __device__ __forceinline__ u32x4 pack(const float (&f)[8]) {
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f16x2_t h;
+      h[0] = (_Float16)f[2 * i];
+      h[1] = (_Float16)f[2 * i + 1];
+      r[i] = __builtin_bit_cast(uint32_t, h);
+    }
+    return r;
+  }
+  static __device__ __forceinline__ float to_float(elem_t v) {
+    return (float)__builtin_bit_cast(_Float16, v);
+  }
+};
+
+// ---------------------------------------------------------------------------
+// lane-group reductions.  Groups are aligned runs of N lanes (N a power of 2).
+// Steps up to 16 lanes ride on DPP modifiers of the add/max itself; wider
+// steps go through ds_bpermute.
+// ---------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+
+// Sum over aligned groups of N lanes; every lane of a group ends with the total.
+template <int N>
+__device__ __forceinline__ float group_sum(float v) {
+  if constexpr (N >= 2) v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]
+  if constexpr (N >= 4) v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]
+  if constexpr (N >= 8) v += dpp_f<0x141>(v);   // row_half_mirror
+  if constexpr (N >= 16) v += dpp_f<0x140>(v);  // row_mirror
+  if constexpr (N >= 32) v += __shfl_xor(v, 16);
+  if constexpr (N >= 64) v += __shfl_xor(v, 32);
+  return v;
+}
+
+// Butterfly over the lane bits ABOVE a group of N lanes: combines lanes
+// l, l^N, l^2N, ... so that lanes with equal (l % N) share the result.
+template <int N, class Op>
+__device__ __forceinline__ float cross_group(float v, Op op) {
+#pragma unroll
+  for (int off = N; off < kWave; off <<= 1) v = op(v, __shfl_xor(v, off));
+  return v;
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+template <bool NT>
+__device__ __forceinline__ u32x4 load16(const void* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+  else return *reinterpret_cast<const u32x4*>(p);
+}
+
+}  // namespace mi355

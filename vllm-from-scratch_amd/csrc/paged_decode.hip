@@ -1,0 +1,548 @@
+// Paged decode attention for MI355X (gfx950).
+//
+// One new query token per sequence attends to that sequence's cached K/V rows,
+// which live in fixed-size physical blocks addressed through a block table.
+// The operation is HBM-bound (about one FLOP per byte), so the kernel is built
+// around keeping many 16-byte-per-lane loads in flight; all arithmetic is VALU
+// (v_dot2c for bf16/f16 scores, fp32 fma for the weighted V sum).
+//
+// Work decomposition
+//   workgroup = (sequence b, token split sp, kv-head group hg, q-head chunk qc)
+//   wave      = one kv head of the group (x one sub-range of the split when the
+//               model has fewer than 8 kv heads)
+//   One wave-load covers 1 KiB: 64 lanes x 16 B = TPL consecutive tokens of one
+//   head, LPT lanes per token row.  With the [block][head][row][d] layout the
+//   8 waves of a workgroup walk the same physical blocks in step, so the 8 head
+//   tiles of a block (contiguous in memory) are fetched together.
+//   Every aligned group of LPT lanes keeps its own online-softmax state
+//   (running max, sum, weighted V) for the tokens it sees, so the loop has no
+//   communication beyond the LPT-lane score reduction; the groups are merged
+//   once at the end, then sub-ranges through LDS, then token splits by a small
+//   second kernel reading fp32 partials from the caller's workspace.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace mi355 {
+namespace {
+
+constexpr int kMaxThreads = 512;
+constexpr int kMaxBtEntries = 8192;  // block-table entries one workgroup may stage in LDS
+constexpr float kNegBig = -1.0e30f;  // running-max start: finite so that exp2(m - m) never sees inf - inf
+
+struct DecodeParams {
+  void* out;
+  const void* q;
+  const void* kc;
+  const void* vc;
+  const int32_t* bt;
+  const int32_t* ctx;
+  const int32_t* cu;  // non-null selects causal mode over packed sequences (see below)
+  int nseq;
+  float* ws_acc;  // [B, Hq, nsplit, D]
+  float* ws_ml;   // [B, Hq, nsplit, 2]  (max in log2 units, sum)
+  int64_t q_stride_seq, s_blk, s_head, s_tok;
+  int B, Hq, Hkv, gq;
+  int block_size, bs_shift, max_blocks, num_blocks, max_ctx;
+  int hpw, sub, hgroups, qchunks, tps, nsplit;
+  int lds_bt_bytes;
+  float scale_log2e;
+};
+
+struct DecodePlan {
+  int nw, hpw, sub, hgroups, G, qchunks, tps, nsplit;
+  size_t lds_bytes, lds_bt_bytes, ws_bytes;
+};
+
+template <class Tag, int D>
+struct Geo {
+  static constexpr int EPL = Tag::kEPL;      // elements per 16-byte lane load
+  static constexpr int LPT = D / EPL;        // lanes per token row
+  static constexpr int TPL = kWave / LPT;    // tokens per wave load
+  static_assert(LPT >= 1 && LPT <= kWave && (LPT & (LPT - 1)) == 0, "unsupported head_dim");
+};
+
+template <class Tag, int D, int G, int U, bool NT>
+__global__ void __launch_bounds__(kMaxThreads) paged_decode_kernel(const DecodeParams p) {
+  constexpr int EPL = Geo<Tag, D>::EPL, LPT = Geo<Tag, D>::LPT, TPL = Geo<Tag, D>::TPL;
+  constexpr int TS = TPL * U;  // tokens per pipeline step of one wave
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int32_t* s_bt = reinterpret_cast<int32_t*>(smem);
+  float* s_part = reinterpret_cast<float*>(smem + p.lds_bt_bytes);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid = blockIdx.x;
+  const int qc = bid % p.qchunks;
+  bid /= p.qchunks;
+  const int hg = bid % p.hgroups;
+  bid /= p.hgroups;
+  const int sp = bid % p.nsplit;
+  const int b = bid / p.nsplit;
+
+  // Causal mode (prompt processing): "sequence" b is query token b of a packed
+  // batch; it attends to tokens start..b of its own prompt, which sit in k/v rows
+  // start..b (block_size 1, physical id = token row).  No block table is read.
+  int ctx, lin_start = 0;
+  if (p.cu) {
+    int lo = 0, hi = p.nseq - 1;
+    while (lo < hi) {  // largest s with cu[s] <= b
+      const int mid = (lo + hi + 1) >> 1;
+      if (p.cu[mid] <= b) lo = mid; else hi = mid - 1;
+    }
+    lin_start = p.cu[lo];
+    ctx = b - lin_start + 1;
+  } else {
+    ctx = max(0, min(p.ctx[b], p.max_ctx));
+  }
+  const int t0 = sp * p.tps;
+  if (p.nsplit > 1 && t0 >= ctx) return;  // the merge kernel skips splits past the context
+  const int wg_end = min(ctx, t0 + p.tps);
+
+  auto block_of = [&](int t) { return p.bs_shift >= 0 ? (t >> p.bs_shift) : (t / p.block_size); };
+
+  // Stage this split's slice of the block table in LDS (ids clamped for memory safety).
+  const int lb0 = block_of(t0);
+  const int nlb = (wg_end > t0 && !p.cu) ? block_of(wg_end - 1) - lb0 + 1 : 0;
+  for (int i = tid; i < nlb; i += blockDim.x) {
+    int id = p.bt[(int64_t)b * p.max_blocks + lb0 + i];
+    s_bt[i] = min(max(id, 0), p.num_blocks - 1);
+  }
+  __syncthreads();
+
+  const int hslot = wave % p.hpw, sb = wave / p.hpw;
+  const int kvh = hg * p.hpw + hslot;
+  const int len_w = p.tps / p.sub;
+  const int tw0 = t0 + sb * len_w;
+  const int tw1 = min(wg_end, tw0 + len_w);
+  const int tl = lane / LPT, dg = lane % LPT;
+
+  // Query fragments: this lane's EPL dims of each of the G query heads.
+  const int hq0 = kvh * p.gq + qc * G;
+  typename Tag::QFrag qf[G];
+#pragma unroll
+  for (int gi = 0; gi < G; ++gi) {
+    const int hq = (qc * G + gi < p.gq) ? hq0 + gi : hq0;
+    const char* src = static_cast<const char*>(p.q) +
+                      ((int64_t)b * p.q_stride_seq + (int64_t)hq * D + dg * EPL) * Tag::kBytes;
+    qf[gi] = Tag::make_q(load16<false>(src));
+  }
+
+  float m[G], l[G], acc[G][EPL];
+#pragma unroll
+  for (int gi = 0; gi < G; ++gi) {
+    m[gi] = kNegBig;
+    l[gi] = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[gi][e] = 0.f;
+  }
+
+  const char* kbase = static_cast<const char*>(p.kc);
+  const char* vbase = static_cast<const char*>(p.vc);
+  const uint32_t lane_off = (uint32_t)kvh * (uint32_t)p.s_head + dg * EPL;  // host checks it fits
+
+  auto load_step = [&](int step, u32x4 (&kb)[U], u32x4 (&vb)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = min(tw0 + step * TS + u * TPL + tl, tw1 - 1);  // rows past the end re-read the last row
+      const int lb = block_of(t);
+      const int row = t - lb * p.block_size;
+      const uint32_t pid = p.cu ? (uint32_t)(lin_start + lb) : (uint32_t)s_bt[lb - lb0];
+      const uint64_t off = ((uint64_t)pid * (uint64_t)p.s_blk + (uint32_t)row * (uint32_t)p.s_tok + lane_off) *
+                           Tag::kBytes;
+      kb[u] = load16<NT>(kbase + off);
+      vb[u] = load16<NT>(vbase + off);
+    }
+  };
+
+  auto compute_step = [&](int step, const u32x4 (&kb)[U], const u32x4 (&vb)[U]) {
+    float sc[G][U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool valid = tw0 + step * TS + u * TPL + tl < tw1;
+#pragma unroll
+      for (int gi = 0; gi < G; ++gi) {
+        const float s = group_sum<LPT>(Tag::dot(qf[gi], kb[u]));
+        sc[gi][u] = valid ? s * p.scale_log2e : -__builtin_inff();
+      }
+    }
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi) {
+      float mx = sc[gi][0];
+#pragma unroll
+      for (int u = 1; u < U; ++u) mx = fmaxf(mx, sc[gi][u]);
+      const float m_new = fmaxf(m[gi], mx);
+      const float f = fast_exp2(m[gi] - m_new);
+      m[gi] = m_new;
+      l[gi] *= f;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) acc[gi][e] *= f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float vf[EPL];
+      Tag::unpack(vb[u], vf);
+#pragma unroll
+      for (int gi = 0; gi < G; ++gi) {
+        const float pr = fast_exp2(sc[gi][u] - m[gi]);
+        l[gi] += pr;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[gi][e] = __builtin_fmaf(pr, vf[e], acc[gi][e]);
+      }
+    }
+  };
+
+  // Two register buffers: the loads of step s+1 are in flight while step s is reduced.
+  const int nsteps = tw1 > tw0 ? (tw1 - tw0 + TS - 1) / TS : 0;
+  u32x4 ka[U], va[U], kb[U], vb[U];
+  if (nsteps > 0) load_step(0, ka, va);
+  for (int s = 0; s < nsteps; s += 2) {
+    if (s + 1 < nsteps) load_step(s + 1, kb, vb);
+    compute_step(s, ka, va);
+    if (s + 2 < nsteps) load_step(s + 2, ka, va);
+    if (s + 1 < nsteps) compute_step(s + 1, kb, vb);
+  }
+
+  // Merge the TPL lane groups of the wave (same dims, different tokens).
+  auto fmax_op = [](float a, float c) { return fmaxf(a, c); };
+  auto add_op = [](float a, float c) { return a + c; };
+#pragma unroll
+  for (int gi = 0; gi < G; ++gi) {
+    const float M = cross_group<LPT>(m[gi], fmax_op);
+    const float f = fast_exp2(m[gi] - M);
+    m[gi] = M;
+    l[gi] = cross_group<LPT>(l[gi] * f, add_op);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[gi][e] = cross_group<LPT>(acc[gi][e] * f, add_op);
+  }
+
+  // Merge the sub-ranges handled by different waves of this workgroup.
+  if (p.sub > 1) {
+    constexpr int kRec = D + 2;
+    float* mine = s_part + (size_t)wave * G * kRec;
+    if (lane < LPT) {
+#pragma unroll
+      for (int gi = 0; gi < G; ++gi) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) mine[gi * kRec + dg * EPL + e] = acc[gi][e];
+        if (lane == 0) {
+          mine[gi * kRec + D] = m[gi];
+          mine[gi * kRec + D + 1] = l[gi];
+        }
+      }
+    }
+    __syncthreads();
+    if (sb == 0 && lane < LPT) {
+      for (int j = 1; j < p.sub; ++j) {
+        const float* other = s_part + (size_t)(hslot + j * p.hpw) * G * kRec;
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+          const float mo = other[gi * kRec + D], lo = other[gi * kRec + D + 1];
+          const float M = fmaxf(m[gi], mo);
+          const float fa = fast_exp2(m[gi] - M), fb = fast_exp2(mo - M);
+          m[gi] = M;
+          l[gi] = l[gi] * fa + lo * fb;
+#pragma unroll
+          for (int e = 0; e < EPL; ++e)
+            acc[gi][e] = acc[gi][e] * fa + other[gi * kRec + dg * EPL + e] * fb;
+        }
+      }
+    }
+  }
+
+  if (sb != 0 || lane >= LPT) return;
+#pragma unroll
+  for (int gi = 0; gi < G; ++gi) {
+    if (qc * G + gi >= p.gq) continue;
+    const int hq = hq0 + gi;
+    if (p.nsplit == 1) {
+      const float inv = l[gi] > 0.f ? 1.f / l[gi] : 0.f;
+      float o[EPL];
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) o[e] = acc[gi][e] * inv;
+      char* dst = static_cast<char*>(p.out) + (((int64_t)b * p.Hq + hq) * D + dg * EPL) * Tag::kBytes;
+      *reinterpret_cast<u32x4*>(dst) = Tag::pack(o);
+    } else {
+      const int64_t rec = ((int64_t)b * p.Hq + hq) * p.nsplit + sp;
+      float* dst = p.ws_acc + rec * D + dg * EPL;
+#pragma unroll
+      for (int e = 0; e < EPL; e += 4)
+        *reinterpret_cast<f32x4*>(dst + e) = f32x4{acc[gi][e], acc[gi][e + 1], acc[gi][e + 2], acc[gi][e + 3]};
+      if (lane == 0) {
+        p.ws_ml[rec * 2] = m[gi];
+        p.ws_ml[rec * 2 + 1] = l[gi];
+      }
+    }
+  }
+}
+
+// Combine the token splits of every (sequence, query head): one thread per 4 output dims.
+template <class Tag, int D>
+__global__ void __launch_bounds__(256) paged_decode_merge_kernel(const DecodeParams p) {
+  constexpr int kVec = 4;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)p.B * p.Hq * (D / kVec);
+  if (idx >= total) return;
+  const int dv = (int)(idx % (D / kVec));
+  const int64_t bh = idx / (D / kVec);
+  const int b = (int)(bh / p.Hq);
+  const int ctx = max(0, min(p.ctx[b], p.max_ctx));
+  const int nvalid = min(p.nsplit, (ctx + p.tps - 1) / p.tps);
+  const float* ml = p.ws_ml + bh * p.nsplit * 2;
+  const float* pa = p.ws_acc + bh * p.nsplit * D + dv * kVec;
+  float M = kNegBig;
+  for (int s = 0; s < nvalid; ++s) M = fmaxf(M, ml[2 * s]);
+  float den = 0.f, o[kVec] = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < nvalid; ++s) {
+    const float f = fast_exp2(ml[2 * s] - M);
+    den = __builtin_fmaf(ml[2 * s + 1], f, den);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(pa + (size_t)s * D);
+#pragma unroll
+    for (int e = 0; e < kVec; ++e) o[e] = __builtin_fmaf(a[e], f, o[e]);
+  }
+  const float inv = den > 0.f ? 1.f / den : 0.f;
+  typename Tag::elem_t* dst = static_cast<typename Tag::elem_t*>(p.out) + bh * D + dv * kVec;
+  if constexpr (Tag::kBytes == 4) {
+    *reinterpret_cast<f32x4*>(dst) = f32x4{o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv};
+  } else {
+    float lo[8] = {o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv, 0.f, 0.f, 0.f, 0.f};
+    const u32x4 packed = Tag::pack(lo);
+    *reinterpret_cast<uint2*>(dst) = make_uint2(packed[0], packed[1]);
+  }
+}
+
+int env_int(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return (s && *s) ? atoi(s) : dflt;
+}
+
+int elems_per_lane(int dtype) { return dtype == MI355_F32 ? 4 : 8; }
+
+constexpr int kU = 4;  // 16-byte loads of K (and of V) per lane per pipeline step
+
+// Launch geometry for a problem shape.  Deterministic in its arguments (plus the
+// MI355_PAGED_TARGET_WGS tuning variable), so the workspace query and the launch agree.
+int make_plan(int B, int Hq, int Hkv, int D, int block_size, int max_context, int dtype,
+              DecodePlan* plan, bool causal = false) {
+  if (B <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv) return fail(MI355_EINVAL, "bad B/Hq/Hkv (%d,%d,%d)", B, Hq, Hkv);
+  if (dtype != MI355_F32 && dtype != MI355_BF16 && dtype != MI355_F16)
+    return fail(MI355_EINVAL, "unknown dtype code %d", dtype);
+  if (D != 16 && D != 32 && D != 64 && D != 128 && D != 256)
+    return fail(MI355_EUNSUPPORTED, "head_dim %d not in {16,32,64,128,256}", D);
+  if (block_size <= 0) return fail(MI355_EINVAL, "block_size %d", block_size);
+  if (max_context < 0) return fail(MI355_EINVAL, "max_context %d", max_context);
+  DecodePlan pl;
+  pl.nw = 8;
+  pl.hpw = (Hkv % 8 == 0) ? 8 : (Hkv % 4 == 0) ? 4 : (Hkv % 2 == 0) ? 2 : 1;
+  pl.sub = pl.nw / pl.hpw;
+  pl.hgroups = Hkv / pl.hpw;
+  const int gq = Hq / Hkv;
+  pl.G = gq >= 8 ? 8 : gq > 2 ? 4 : gq;  // 1, 2, 4 or 8 query heads per wave
+  pl.qchunks = (gq + pl.G - 1) / pl.G;
+  const int lpt = D / elems_per_lane(dtype);
+  const int ts = (kWave / lpt) * kU;
+  const int quantum = pl.sub * ts;  // tokens one workgroup consumes per pipeline step
+  const int ctx = max_context > 0 ? max_context : 1;
+  const int64_t base_wgs = (int64_t)B * pl.hgroups * pl.qchunks;
+  const int target = env_int("MI355_PAGED_TARGET_WGS", 1024);
+  int64_t want = ceil_div64(target, base_wgs);
+  const int64_t most = ctx / (2 * quantum) > 0 ? ctx / (2 * quantum) : 1;  // >= 2 steps per wave
+  if (want > most) want = most;
+  if (want < 1 || causal) want = 1;  // causal mode: one workgroup per query row, no token split
+  int64_t tps = ceil_div64(ceil_div64(ctx, want), quantum) * quantum;
+  if (!causal) {
+    const int64_t tps_cap = ((int64_t)(kMaxBtEntries - 2) * block_size / quantum) * quantum;
+    if (tps_cap < quantum)
+      return fail(MI355_EUNSUPPORTED, "block_size %d too small for head_dim %d", block_size, D);
+    if (tps > tps_cap) tps = tps_cap;
+  }
+  pl.tps = (int)tps;
+  pl.nsplit = (int)ceil_div64(ctx, tps);
+  pl.lds_bt_bytes = causal ? 16 : (size_t)((tps / block_size + 2) * 4 + 15) / 16 * 16;
+  pl.lds_bytes = pl.lds_bt_bytes + (pl.sub > 1 ? (size_t)pl.nw * pl.G * (D + 2) * 4 : 0);
+  pl.ws_bytes = pl.nsplit > 1 ? (size_t)B * Hq * pl.nsplit * (D + 2) * sizeof(float) : 0;
+  *plan = pl;
+  return 0;
+}
+
+#ifndef MI355_DECODE_NT
+#define MI355_DECODE_NT 1
+#endif
+
+template <class Tag, int D, int G>
+int launch_decode(const DecodeParams& p, const DecodePlan& pl, hipStream_t stream) {
+  const int64_t grid = (int64_t)p.B * p.nsplit * p.hgroups * p.qchunks;
+  hipLaunchKernelGGL((paged_decode_kernel<Tag, D, G, kU, MI355_DECODE_NT != 0>), dim3((unsigned)grid),
+                     dim3(pl.nw * kWave), pl.lds_bytes, stream, p);
+  if (int rc = check_launch("paged_decode_kernel")) return rc;
+  if (p.nsplit > 1) {
+    const int64_t threads = (int64_t)p.B * p.Hq * (D / 4);
+    hipLaunchKernelGGL((paged_decode_merge_kernel<Tag, D>), dim3((unsigned)ceil_div64(threads, 256)), dim3(256),
+                       0, stream, p);
+    return check_launch("paged_decode_merge_kernel");
+  }
+  return 0;
+}
+
+template <class Tag, int D>
+int dispatch_g(const DecodeParams& p, const DecodePlan& pl, hipStream_t s) {
+  switch (pl.G) {
+    case 1: return launch_decode<Tag, D, 1>(p, pl, s);
+    case 2: return launch_decode<Tag, D, 2>(p, pl, s);
+    case 4: return launch_decode<Tag, D, 4>(p, pl, s);
+    case 8: return launch_decode<Tag, D, 8>(p, pl, s);
+  }
+  return fail(MI355_EUNSUPPORTED, "query group %d", pl.G);
+}
+
+template <class Tag>
+int dispatch_d(int D, const DecodeParams& p, const DecodePlan& pl, hipStream_t s) {
+  switch (D) {
+    case 16: return dispatch_g<Tag, 16>(p, pl, s);
+    case 32: return dispatch_g<Tag, 32>(p, pl, s);
+    case 64: return dispatch_g<Tag, 64>(p, pl, s);
+    case 128: return dispatch_g<Tag, 128>(p, pl, s);
+    case 256: return dispatch_g<Tag, 256>(p, pl, s);
+  }
+  return fail(MI355_EUNSUPPORTED, "head_dim %d", D);
+}
+
+}  // namespace
+}  // namespace mi355
+
+using namespace mi355;
+
+extern "C" size_t mi355_paged_decode_workspace_bytes(int32_t B, int32_t Hq, int32_t Hkv, int32_t D,
+                                                     int32_t block_size, int32_t max_context,
+                                                     int32_t dtype) {
+  DecodePlan pl;
+  if (make_plan(B, Hq, Hkv, D, block_size, max_context, dtype, &pl)) return 0;
+  return pl.ws_bytes;
+}
+
+extern "C" int mi355_paged_decode(void* out, const void* q, int64_t q_stride_seq, const void* k_cache,
+                                  const void* v_cache, const int32_t* block_tables,
+                                  const int32_t* context_lens, int32_t B, int32_t Hq, int32_t Hkv,
+                                  int32_t D, int32_t block_size, int32_t max_blocks, int32_t num_blocks,
+                                  int32_t max_context, int64_t kv_stride_block, int64_t kv_stride_head,
+                                  int64_t kv_stride_tok, float scale, int32_t dtype, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  if (B == 0) return 0;
+  if (!out || !q || !k_cache || !v_cache || !block_tables || !context_lens)
+    return fail(MI355_EINVAL, "paged_decode: null pointer argument");
+  if (max_blocks <= 0 || num_blocks <= 0) return fail(MI355_EINVAL, "paged_decode: max_blocks/num_blocks");
+  if ((int64_t)max_context > (int64_t)max_blocks * block_size) max_context = max_blocks * block_size;
+  DecodePlan pl;
+  if (int rc = make_plan(B, Hq, Hkv, D, block_size, max_context, dtype, &pl)) return rc;
+  const int epl = elems_per_lane(dtype);
+  const int64_t esz = dtype == MI355_F32 ? 4 : 2;
+  if (kv_stride_block <= 0 || kv_stride_head < 0 || kv_stride_tok <= 0 || kv_stride_block >= (1LL << 31) ||
+      kv_stride_tok >= (1LL << 31) || (int64_t)Hkv * kv_stride_head + D >= (1LL << 31))
+    return fail(MI355_EINVAL, "paged_decode: kv strides out of range");
+  if (kv_stride_block % epl || kv_stride_head % epl || kv_stride_tok % epl || q_stride_seq % epl ||
+      q_stride_seq < (int64_t)Hq * D)
+    return fail(MI355_EINVAL, "paged_decode: strides must keep head rows 16-byte aligned");
+  if (((uintptr_t)out | (uintptr_t)q | (uintptr_t)k_cache | (uintptr_t)v_cache) & 15)
+    return fail(MI355_EINVAL, "paged_decode: tensors must be 16-byte aligned");
+  (void)esz;
+  if (pl.ws_bytes && (!workspace || workspace_bytes < pl.ws_bytes || ((uintptr_t)workspace & 15)))
+    return fail(MI355_EWORKSPACE, "paged_decode: need %zu workspace bytes (16-B aligned), got %zu",
+                pl.ws_bytes, workspace ? workspace_bytes : (size_t)0);
+
+  DecodeParams p;
+  p.out = out;
+  p.q = q;
+  p.kc = k_cache;
+  p.vc = v_cache;
+  p.bt = block_tables;
+  p.ctx = context_lens;
+  p.cu = nullptr;
+  p.nseq = 0;
+  p.ws_acc = static_cast<float*>(workspace);
+  p.ws_ml = p.ws_acc ? p.ws_acc + (size_t)B * Hq * pl.nsplit * D : nullptr;
+  p.q_stride_seq = q_stride_seq;
+  p.s_blk = kv_stride_block;
+  p.s_head = kv_stride_head;
+  p.s_tok = kv_stride_tok;
+  p.B = B;
+  p.Hq = Hq;
+  p.Hkv = Hkv;
+  p.gq = Hq / Hkv;
+  p.block_size = block_size;
+  p.bs_shift = ilog2_exact(block_size);
+  p.max_blocks = max_blocks;
+  p.num_blocks = num_blocks;
+  p.max_ctx = max_context;
+  p.hpw = pl.hpw;
+  p.sub = pl.sub;
+  p.hgroups = pl.hgroups;
+  p.qchunks = pl.qchunks;
+  p.tps = pl.tps;
+  p.nsplit = pl.nsplit;
+  p.lds_bt_bytes = (int)pl.lds_bt_bytes;
+  p.scale_log2e = scale * 1.4426950408889634f;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case MI355_F32: return dispatch_d<F32>(D, p, pl, s);
+    case MI355_BF16: return dispatch_d<BF16>(D, p, pl, s);
+    case MI355_F16: return dispatch_d<F16>(D, p, pl, s);
+  }
+  return fail(MI355_EINVAL, "paged_decode: dtype %d", dtype);
+}
+
+extern "C" int mi355_prefill_causal(void* out, const void* q, const void* k, const void* v,
+                                    int64_t q_stride_tok, int64_t kv_stride_tok, const int32_t* cu_seqlens,
+                                    int32_t nseq, int32_t total_tokens, int32_t max_seqlen, int32_t Hq,
+                                    int32_t Hkv, int32_t D, float scale, int32_t dtype, void* stream) {
+  // Runs the decode kernel in causal mode: every query token is one row whose
+  // context is the packed k/v rows of its own prompt up to and including itself.
+  if (total_tokens == 0 || nseq == 0) return 0;
+  if (!out || !q || !k || !v || !cu_seqlens) return fail(MI355_EINVAL, "prefill_causal: null pointer");
+  if (total_tokens < 0 || nseq < 0 || max_seqlen <= 0) return fail(MI355_EINVAL, "prefill_causal: bad sizes");
+  DecodePlan pl;
+  if (int rc = make_plan(total_tokens, Hq, Hkv, D, 1, max_seqlen, dtype, &pl, /*causal=*/true)) return rc;
+  const int epl = elems_per_lane(dtype);
+  if (q_stride_tok % epl || kv_stride_tok % epl || q_stride_tok < (int64_t)Hq * D ||
+      kv_stride_tok < (int64_t)Hkv * D || kv_stride_tok >= (1LL << 31))
+    return fail(MI355_EINVAL, "prefill_causal: strides must keep head rows 16-byte aligned");
+  if (((uintptr_t)out | (uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15)
+    return fail(MI355_EINVAL, "prefill_causal: tensors must be 16-byte aligned");
+  DecodeParams p;
+  p.out = out;
+  p.q = q;
+  p.kc = k;
+  p.vc = v;
+  p.bt = nullptr;
+  p.ctx = nullptr;
+  p.cu = cu_seqlens;
+  p.nseq = nseq;
+  p.ws_acc = nullptr;
+  p.ws_ml = nullptr;
+  p.q_stride_seq = q_stride_tok;
+  p.s_blk = kv_stride_tok;  // "block" = one token row
+  p.s_head = D;
+  p.s_tok = 0;
+  p.B = total_tokens;
+  p.Hq = Hq;
+  p.Hkv = Hkv;
+  p.gq = Hq / Hkv;
+  p.block_size = 1;
+  p.bs_shift = 0;
+  p.max_blocks = max_seqlen;
+  p.num_blocks = total_tokens;
+  p.max_ctx = max_seqlen;
+  p.hpw = pl.hpw;
+  p.sub = pl.sub;
+  p.hgroups = pl.hgroups;
+  p.qchunks = pl.qchunks;
+  p.tps = pl.tps;
+  p.nsplit = 1;
+  p.lds_bt_bytes = (int)pl.lds_bt_bytes;
+  p.scale_log2e = scale * 1.4426950408889634f;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case MI355_F32: return dispatch_d<F32>(D, p, pl, s);
+    case MI355_BF16: return dispatch_d<BF16>(D, p, pl, s);
+    case MI355_F16: return dispatch_d<F16>(D, p, pl, s);
+  }
+  return fail(MI355_EINVAL, "prefill_causal: dtype %d", dtype);
+}

@@ -1,0 +1,402 @@
+// Token sampling kernels: greedy argmax and temperature / top-k / top-p sampling.
+//
+// One workgroup owns one row of logits.  Row maxima, argmax pairs, probability
+// sums and counts are reduced with wave shuffles first and a small LDS exchange
+// across the waves of the workgroup second.
+#include <math.h>
+
+#include "common.h"
+
+namespace mi355 {
+namespace {
+
+constexpr int kMaxWaves = 16;
+
+template <class T, class Op>
+__device__ __forceinline__ T wave_reduce(T v, Op op) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = op(v, __shfl_xor(v, off));
+  return v;
+}
+
+// All threads get the reduction over the workgroup.  scratch: kMaxWaves entries in LDS.
+template <class T, class Op>
+__device__ __forceinline__ T block_reduce(T v, Op op, T* scratch) {
+  v = wave_reduce(v, op);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if (lane == 0) scratch[wave] = v;
+  __syncthreads();
+  T r = scratch[0];
+  for (int w = 1; w < nw; ++w) r = op(r, scratch[w]);
+  __syncthreads();
+  return r;
+}
+
+// ------------------------------------------------------------------ argmax
+// Candidate = (value, index).  Order: NaN beats every number, larger beats
+// smaller, and between equals (or two NaNs) the lower index wins -- the result
+// torch.argmax returns.
+struct Cand {
+  float v;
+  int i;
+};
+
+__device__ __forceinline__ bool cand_better(float av, int ai, float bv, int bi) {
+  const bool an = av != av, bn = bv != bv;
+  if (an != bn) return an;
+  if (!an && av != bv) return av > bv;
+  return ai < bi;
+}
+
+template <class Tag>
+__global__ void __launch_bounds__(512)
+argmax_kernel(int32_t* out, const typename Tag::elem_t* logits, int vocab, int64_t row_stride, int vec_ok) {
+  constexpr int EPL = Tag::kEPL;
+  __shared__ float s_v[kMaxWaves];
+  __shared__ int s_i[kMaxWaves];
+  const typename Tag::elem_t* row = logits + (int64_t)blockIdx.x * row_stride;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  // Per thread: running maximum over numbers (first occurrence) and first NaN seen.
+  float best = -__builtin_inff();
+  int best_i = 0x7fffffff, nan_i = 0x7fffffff;
+  auto visit = [&](float x, int idx) {
+    if (x != x) {
+      nan_i = min(nan_i, idx);
+    } else if (x > best || best_i == 0x7fffffff) {
+      best = x;
+      best_i = idx;
+    }
+  };
+  const int nvec = vec_ok ? vocab / EPL : 0;
+  for (int c = tid; c < nvec; c += nt) {
+    float f[EPL];
+    Tag::unpack(*reinterpret_cast<const u32x4*>(row + (int64_t)c * EPL), f);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) visit(f[e], c * EPL + e);
+  }
+  for (int idx = nvec * EPL + tid; idx < vocab; idx += nt) visit(Tag::to_float(row[idx]), idx);
+
+  float cv = nan_i != 0x7fffffff ? __builtin_nanf("") : best;
+  int ci = nan_i != 0x7fffffff ? nan_i : best_i;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float ov = __shfl_xor(cv, off);
+    const int oi = __shfl_xor(ci, off);
+    if (cand_better(ov, oi, cv, ci)) {
+      cv = ov;
+      ci = oi;
+    }
+  }
+  const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+  if (lane == 0) {
+    s_v[wave] = cv;
+    s_i[wave] = ci;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < nw; ++w)
+      if (cand_better(s_v[w], s_i[w], cv, ci)) {
+        cv = s_v[w];
+        ci = s_i[w];
+      }
+    out[blockIdx.x] = ci == 0x7fffffff ? 0 : ci;
+  }
+}
+
+// ------------------------------------------------------------------ philox
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+  c[1] = (uint32_t)p1;
+  c[3] = (uint32_t)p0;
+  c[0] = n0;
+  c[2] = n2;
+}
+
+// Philox4x32-10: uniform in [0,1) from (seed, counter).
+__device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t counter) {
+  uint32_t c[4] = {(uint32_t)counter, (uint32_t)(counter >> 32), 0u, 0u};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return (float)(c[0] >> 8) * (1.0f / 16777216.0f);
+}
+
+// ------------------------------------------------------------------ sampling
+struct SampleParams {
+  int32_t* out;
+  const void* logits;
+  const float* temperature;
+  const float* top_p;
+  const int32_t* top_k;
+  float* out_probs;
+  uint64_t seed, offset;
+  int vocab;
+  int64_t row_stride;
+};
+
+struct FC {  // (probability mass, count) pair reduced together
+  float f;
+  int c;
+};
+
+// VPT > 0: the row's probabilities live in registers (VPT per thread).
+// VPT == 0: they are recomputed from the logits on every pass (any vocab size).
+template <class Tag, int VPT, int NT>
+__global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
+  __shared__ float s_f[kMaxWaves];
+  __shared__ int s_c[kMaxWaves];
+  __shared__ int s_pick;
+  const int tid = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+  const typename Tag::elem_t* row = static_cast<const typename Tag::elem_t*>(p.logits) + (int64_t)b * p.row_stride;
+  const int vocab = p.vocab;
+  const float temp = p.temperature[b];
+  const float tp = p.top_p ? p.top_p[b] : 1.0f;
+  const int tk = p.top_k ? p.top_k[b] : 0;
+  auto fmaxop = [](float a, float c) { return fmaxf(a, c); };
+  auto fminop = [](float a, float c) { return fminf(a, c); };
+  auto addf = [](float a, float c) { return a + c; };
+  auto addi = [](int a, int c) { return a + c; };
+  auto maxi = [](int a, int c) { return max(a, c); };
+
+  // temperature-scaled logits: y = x / T, as the reference divides before softmax
+  float mx = -__builtin_inff();
+  for (int i = tid; i < vocab; i += nt) mx = fmaxf(mx, Tag::to_float(row[i]) / temp);
+  mx = block_reduce(mx, fmaxop, s_f);
+  float z = 0.f;
+  for (int i = tid; i < vocab; i += nt) z += expf(Tag::to_float(row[i]) / temp - mx);
+  z = block_reduce(z, addf, s_f);
+
+  auto prob_at = [&](int i) { return expf(Tag::to_float(row[i]) / temp - mx) / z; };
+  constexpr int NR = VPT > 0 ? VPT : 1;
+  float pr[NR];
+  if constexpr (VPT > 0) {
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+      const int i = j * nt + tid;
+      pr[j] = i < vocab ? prob_at(i) : -1.0f;  // -1 marks "no element"
+    }
+  }
+  // Visits every element this thread owns: fn(probability, index).
+  auto for_each = [&](auto fn) {
+    if constexpr (VPT > 0) {
+#pragma unroll
+      for (int j = 0; j < VPT; ++j)
+        if (pr[j] >= 0.f) fn(pr[j], j * nt + tid);
+    } else {
+      for (int i = tid; i < vocab; i += nt) fn(prob_at(i), i);
+    }
+  };
+  // (mass, count) of elements strictly above v, over the whole row.
+  auto above = [&](float v) {
+    FC a = {0.f, 0};
+    for_each([&](float q, int) {
+      if (q > v) {
+        a.f += q;
+        a.c += 1;
+      }
+    });
+    a.f = wave_reduce(a.f, addf);
+    a.c = wave_reduce(a.c, addi);
+    if (lane == 0) {
+      s_f[wave] = a.f;
+      s_c[wave] = a.c;
+    }
+    __syncthreads();
+    FC r = {s_f[0], s_c[0]};
+    for (int w = 1; w < nw; ++w) {
+      r.f += s_f[w];
+      r.c += s_c[w];
+    }
+    __syncthreads();
+    return r;
+  };
+
+  // Cut: elements with probability > vstar are kept, and of those equal to vstar
+  // the ones with index < tie_end.  Default keeps everything.
+  float vstar = -1.0f, kept_mass;
+  int tie_end = vocab;
+  const bool filter = tp < 1.0f || tk > 0;
+  if (!filter) {
+    float s = 0.f;
+    for_each([&](float q, int) { s += q; });
+    kept_mass = block_reduce(s, addf, s_f);
+  } else {
+    const int kk = tk > 0 ? tk : 0x7fffffff;
+    // A value v survives (its first copy in descending order is kept) iff the mass
+    // strictly above it is < top_p and fewer than k elements are above it.  That
+    // predicate is monotone in v, so bisect on the bit pattern of a non-negative float.
+    float pmax = 0.f;
+    for_each([&](float q, int) { pmax = fmaxf(pmax, q); });
+    pmax = block_reduce(pmax, fmaxop, s_f);
+    uint32_t lo = 0u, hi = __builtin_bit_cast(uint32_t, pmax);
+    while (lo < hi) {
+      const uint32_t mid = lo + ((hi - lo) >> 1);
+      const FC a = above(__builtin_bit_cast(float, mid));
+      if (a.f < tp && a.c < kk) hi = mid; else lo = mid + 1;
+    }
+    const float u = __builtin_bit_cast(float, lo);
+    float vmin = __builtin_inff();
+    for_each([&](float q, int) {
+      if (q >= u) vmin = fminf(vmin, q);
+    });
+    vstar = block_reduce(vmin, fminop, s_f);
+    const FC a = above(vstar);
+    int ties = 0;
+    for_each([&](float q, int) { ties += (q == vstar); });
+    ties = block_reduce(ties, addi, s_c);
+    // Number of tied copies kept: copy j (0-based) needs mass_above + j*v < top_p and count_above + j < k.
+    int keep = ties;
+    if (tp < 1.0f && vstar > 0.f) {
+      int jp = (int)fminf(ceilf((tp - a.f) / vstar), 2.0e9f);
+      while (jp > 0 && !(a.f + (float)(jp - 1) * vstar < tp)) --jp;
+      while (jp < ties && (a.f + (float)jp * vstar < tp)) ++jp;
+      keep = min(keep, jp);
+    }
+    if (tk > 0) keep = min(keep, kk - a.c);
+    keep = max(keep, a.c == 0 ? 1 : 0);
+    if (keep < ties) {
+      // Keep the `keep` lowest-index copies: smallest X with #(ties at index < X) >= keep.
+      int xl = 1, xh = vocab;
+      while (xl < xh) {
+        const int xm = xl + ((xh - xl) >> 1);
+        int c = 0;
+        for_each([&](float q, int i) { c += (q == vstar && i < xm); });
+        c = block_reduce(c, addi, s_c);
+        if (c >= keep) xh = xm; else xl = xm + 1;
+      }
+      tie_end = xl;
+    }
+    kept_mass = a.f + (float)keep * vstar;
+  }
+  auto is_kept = [&](float q, int i) { return q > vstar || (q == vstar && i < tie_end); };
+
+  if (p.out_probs) {
+    float* dst = p.out_probs + (int64_t)b * vocab;
+    for_each([&](float q, int i) { dst[i] = is_kept(q, i) ? q / kept_mass : 0.f; });
+  }
+
+  // One draw.  Kept mass is walked thread by thread (any fixed order gives the
+  // same distribution): exclusive scan of per-thread kept sums, the thread whose
+  // interval contains the target walks its own elements.
+  const float target = philox_uniform(p.seed, p.offset + (uint64_t)b) * kept_mass;
+  float mine = 0.f;
+  int last_kept = -1;
+  for_each([&](float q, int i) {
+    if (is_kept(q, i)) {
+      mine += q;
+      last_kept = max(last_kept, i);
+    }
+  });
+  float incl = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float o = __shfl_up(incl, off);
+    if (lane >= off) incl += o;
+  }
+  if (lane == 63) s_f[wave] = incl;
+  if (tid == 0) s_pick = 0x7fffffff;
+  __syncthreads();
+  float base = 0.f;
+  for (int w = 0; w < wave; ++w) base += s_f[w];
+  const float excl = base + incl - mine;
+  if (mine > 0.f && excl <= target && target < excl + mine) atomicMin(&s_pick, tid);
+  __syncthreads();
+  const int picker = s_pick;
+  last_kept = block_reduce(last_kept, maxi, s_c);
+  if (picker == 0x7fffffff) {
+    if (tid == 0) p.out[b] = max(last_kept, 0);  // rounding pushed the target past the total
+    return;
+  }
+  if (tid == picker) {
+    float run = excl;
+    int choice = -1, fallback = -1;
+    for_each([&](float q, int i) {
+      if (is_kept(q, i)) {
+        fallback = i;
+        run += q;
+        if (choice < 0 && run > target) choice = i;
+      }
+    });
+    p.out[b] = choice >= 0 ? choice : fallback;
+  }
+}
+
+template <class Tag>
+int launch_sample(const SampleParams& p, int B, hipStream_t s) {
+  const int v = p.vocab;
+  // Register-resident rows up to 32768 entries (512 threads may use 256 VGPRs each,
+  // 1024 threads only 128); longer rows are recomputed from the logits on every pass.
+  if (v <= 4 * 256) hipLaunchKernelGGL((sample_kernel<Tag, 4, 256>), dim3(B), dim3(256), 0, s, p);
+  else if (v <= 16 * 1024) hipLaunchKernelGGL((sample_kernel<Tag, 16, 1024>), dim3(B), dim3(1024), 0, s, p);
+  else if (v <= 64 * 512) hipLaunchKernelGGL((sample_kernel<Tag, 64, 512>), dim3(B), dim3(512), 0, s, p);
+  else hipLaunchKernelGGL((sample_kernel<Tag, 0, 1024>), dim3(B), dim3(1024), 0, s, p);
+  return check_launch("sample_kernel");
+}
+
+}  // namespace
+}  // namespace mi355
+
+using namespace mi355;
+
+extern "C" int mi355_sample_argmax(int32_t* out_ids, const void* logits, int32_t B, int32_t vocab,
+                                   int64_t row_stride, int32_t dtype, void* stream) {
+  if (B == 0) return 0;
+  if (!out_ids || !logits) return fail(MI355_EINVAL, "sample_argmax: null pointer");
+  if (B < 0 || vocab <= 0 || row_stride < vocab) return fail(MI355_EINVAL, "sample_argmax: bad shape");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int threads = vocab >= 8192 ? 512 : vocab >= 1024 ? 256 : 64;
+  const int ebytes = dtype == MI355_F32 ? 4 : 2;
+  const int vec_ok = (((uintptr_t)logits & 15) == 0) && ((row_stride * ebytes) % 16 == 0);
+  switch (dtype) {
+    case MI355_F32:
+      hipLaunchKernelGGL(argmax_kernel<F32>, dim3(B), dim3(threads), 0, s, out_ids,
+                         static_cast<const float*>(logits), vocab, row_stride, vec_ok);
+      break;
+    case MI355_BF16:
+      hipLaunchKernelGGL(argmax_kernel<BF16>, dim3(B), dim3(threads), 0, s, out_ids,
+                         static_cast<const uint16_t*>(logits), vocab, row_stride, vec_ok);
+      break;
+    case MI355_F16:
+      hipLaunchKernelGGL(argmax_kernel<F16>, dim3(B), dim3(threads), 0, s, out_ids,
+                         static_cast<const uint16_t*>(logits), vocab, row_stride, vec_ok);
+      break;
+    default:
+      return fail(MI355_EINVAL, "sample_argmax: dtype %d", dtype);
+  }
+  return check_launch("argmax_kernel");
+}
+
+extern "C" int mi355_sample_topk_topp(int32_t* out_ids, const void* logits, const float* temperature,
+                                      const float* top_p, const int32_t* top_k, uint64_t seed,
+                                      uint64_t offset, int32_t B, int32_t vocab, int64_t row_stride,
+                                      int32_t dtype, float* out_probs, void* stream) {
+  if (B == 0) return 0;
+  if (!out_ids || !logits || !temperature) return fail(MI355_EINVAL, "sample_topk_topp: null pointer");
+  if (B < 0 || vocab <= 0 || row_stride < vocab) return fail(MI355_EINVAL, "sample_topk_topp: bad shape");
+  SampleParams p;
+  p.out = out_ids;
+  p.logits = logits;
+  p.temperature = temperature;
+  p.top_p = top_p;
+  p.top_k = top_k;
+  p.out_probs = out_probs;
+  p.seed = seed;
+  p.offset = offset;
+  p.vocab = vocab;
+  p.row_stride = row_stride;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case MI355_F32: return launch_sample<F32>(p, B, s);
+    case MI355_BF16: return launch_sample<BF16>(p, B, s);
+    case MI355_F16: return launch_sample<F16>(p, B, s);
+  }
+  return fail(MI355_EINVAL, "sample_topk_topp: dtype %d", dtype);
+}

@@ -1,0 +1,269 @@
+"""Tensor-level wrappers over the C ABI: torch tensors in, torch tensors out.
+
+torch is used for device memory, streams and dtype bookkeeping only; every
+operation here is one call into libmi355_paged.so on the tensor's HIP device.
+Tensors must already live on the device -- the drop-in modules
+(paged_attention.py / mini_vllm.py) do the staging for host tensors.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+_DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+SUPPORTED_HEAD_DIMS = (16, 32, 64, 128, 256)
+
+# KV cache layouts, as (block, head, token) dimension indices of a 4-D cache tensor:
+#   'NHSD' = [num_blocks, kv_heads, block_size, head_dim]   (KVCachePool.kv_cache[0|1, layer])
+#   'NSHD' = [num_blocks, block_size, heads, head_dim]      (MiniTransformer.k_cache[layer])
+_LAYOUT_DIMS = {'NHSD': (0, 1, 2), 'NSHD': (0, 2, 1)}
+
+_workspaces = {}
+
+
+def dtype_code(t: torch.Tensor) -> int:
+    try:
+        return _DTYPE_CODE[t.dtype]
+    except KeyError:
+        raise TypeError(f"mi355_paged: unsupported dtype {t.dtype}; use float32, bfloat16 or float16")
+
+
+def require_device(*tensors: torch.Tensor) -> torch.device:
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("mi355_paged: tensors must live on a HIP device (torch device 'cuda'); "
+                               "this path has no CPU implementation")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"mi355_paged: tensors on different devices ({dev} vs {t.device})")
+    return dev
+
+
+def _stream(dev: torch.device) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _workspace(dev: torch.device, nbytes: int) -> Tuple[Optional[torch.Tensor], int]:
+    """A per-device scratch tensor that only ever grows (torch owns the memory)."""
+    if nbytes == 0:
+        return None, 0
+    ws = _workspaces.get(dev)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+        _workspaces[dev] = ws
+    return ws, ws.numel()
+
+
+def _stride(t: torch.Tensor, dim: int) -> int:
+    """Stride of `dim`; a size-1 dim may carry any stride, so report the contiguous one."""
+    if t.shape[dim] != 1:
+        return t.stride(dim)
+    n = 1
+    for d in range(dim + 1, t.dim()):
+        n *= t.shape[d]
+    return n
+
+
+def _kv_geometry(cache: torch.Tensor, layout: str):
+    if cache.dim() != 4:
+        raise ValueError(f"KV cache must be 4-D ({layout}), got shape {tuple(cache.shape)}")
+    if cache.stride(3) != 1:
+        raise ValueError("KV cache head rows must be contiguous (stride of the last dim == 1)")
+    bi, hi, ti = _LAYOUT_DIMS[layout]
+    return dict(num_blocks=cache.shape[bi], heads=cache.shape[hi], block_size=cache.shape[ti],
+                head_dim=cache.shape[3], s_block=_stride(cache, bi), s_head=_stride(cache, hi),
+                s_tok=_stride(cache, ti))
+
+
+def paged_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                 block_tables: torch.Tensor, context_lens: torch.Tensor, max_context: int,
+                 layout: str = 'NHSD', scale: Optional[float] = None,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Batched paged decode attention.
+
+    q [B, Hq, D]; k_cache / v_cache 4-D in `layout`; block_tables [B, max_blocks] int32;
+    context_lens [B] int32; max_context = host-side upper bound of context_lens.
+    Returns out [B, Hq, D] in q's dtype.
+    """
+    dev = require_device(q, k_cache, v_cache, block_tables, context_lens)
+    lib = _lib.load()
+    if q.dim() != 3 or q.stride(2) != 1 or q.stride(1) != q.shape[2]:
+        q = q.contiguous()
+    B, Hq, D = q.shape
+    g = _kv_geometry(k_cache, layout)
+    if tuple(v_cache.shape) != tuple(k_cache.shape) or _kv_geometry(v_cache, layout) != g:
+        raise ValueError("k_cache and v_cache must share shape and strides")
+    if k_cache.dtype != q.dtype or v_cache.dtype != q.dtype:
+        raise TypeError("query and KV cache dtypes differ")
+    if g['head_dim'] != D:
+        raise ValueError(f"head_dim mismatch: q {D}, cache {g['head_dim']}")
+    if block_tables.dtype != torch.int32 or context_lens.dtype != torch.int32:
+        raise TypeError("block_tables and context_lens must be int32")
+    block_tables = block_tables.contiguous()
+    context_lens = context_lens.contiguous()
+    if block_tables.dim() != 2 or block_tables.shape[0] != B or context_lens.numel() != B:
+        raise ValueError("block_tables must be [B, max_blocks] and context_lens [B]")
+    if out is None:
+        out = torch.empty((B, Hq, D), dtype=q.dtype, device=dev)
+    code = dtype_code(q)
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    with torch.cuda.device(dev):
+        need = lib.mi355_paged_decode_workspace_bytes(B, Hq, g['heads'], D, g['block_size'],
+                                                      int(max_context), code)
+        ws, ws_bytes = _workspace(dev, need)
+        rc = lib.mi355_paged_decode(
+            out.data_ptr(), q.data_ptr(), _stride(q, 0), k_cache.data_ptr(), v_cache.data_ptr(),
+            block_tables.data_ptr(), context_lens.data_ptr(), B, Hq, g['heads'], D,
+            g['block_size'], block_tables.shape[1], g['num_blocks'], int(max_context),
+            g['s_block'], g['s_head'], g['s_tok'], float(scale), code,
+            ws.data_ptr() if ws is not None else None, ws_bytes, _stream(dev))
+    _lib.check(rc, 'mi355_paged_decode')
+    return out
+
+
+def kv_write_slots(k_cache: torch.Tensor, v_cache: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
+                   slots: torch.Tensor, layout: str = 'NHSD') -> None:
+    """cache[slot // BS, :, slot % BS, :] = row, for T rows; k, v [T, Hkv, D]; slots [T] int64."""
+    dev = require_device(k_cache, v_cache, k, v, slots)
+    lib = _lib.load()
+    g = _kv_geometry(k_cache, layout)
+    if tuple(v_cache.shape) != tuple(k_cache.shape) or _kv_geometry(v_cache, layout) != g:
+        raise ValueError("k_cache and v_cache must share shape and strides")
+    if k.dtype != k_cache.dtype or v.dtype != k_cache.dtype:
+        raise TypeError("new K/V rows and the cache differ in dtype")
+
+    def rows(t):
+        if t.dim() != 3 or t.stride(2) != 1 or t.stride(1) != t.shape[2]:
+            t = t.contiguous()
+        return t
+
+    k, v = rows(k), rows(v)
+    if _stride(v, 0) != _stride(k, 0):
+        k, v = k.contiguous(), v.contiguous()
+    T, H, D = k.shape
+    if H != g['heads'] or D != g['head_dim'] or tuple(v.shape) != (T, H, D):
+        raise ValueError("k/v must be [T, kv_heads, head_dim] matching the cache")
+    if slots.dtype != torch.int64:
+        slots = slots.to(torch.int64)
+    slots = slots.contiguous()
+    if slots.numel() != T:
+        raise ValueError("one slot per token expected")
+    with torch.cuda.device(dev):
+        rc = lib.mi355_kv_write_slots(
+            k_cache.data_ptr(), v_cache.data_ptr(), k.data_ptr(), v.data_ptr(), slots.data_ptr(),
+            T, H, D, _stride(k, 0), g['block_size'], g['num_blocks'], g['s_block'], g['s_head'],
+            g['s_tok'], dtype_code(k), _stream(dev))
+    _lib.check(rc, 'mi355_kv_write_slots')
+
+
+def prefill_causal(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_seqlens: torch.Tensor,
+                   max_seqlen: int, scale: Optional[float] = None) -> torch.Tensor:
+    """Causal attention over packed sequences. q [T, Hq, D]; k, v [T, Hkv, D];
+    cu_seqlens [nseq + 1] int32 (device). Returns [T, Hq, D]."""
+    dev = require_device(q, k, v, cu_seqlens)
+    lib = _lib.load()
+
+    def rows(t):
+        if t.dim() != 3 or t.stride(2) != 1 or t.stride(1) != t.shape[2]:
+            t = t.contiguous()
+        return t
+
+    q, k, v = rows(q), rows(k), rows(v)
+    if _stride(v, 0) != _stride(k, 0):
+        k, v = k.contiguous(), v.contiguous()
+    T, Hq, D = q.shape
+    Hkv = k.shape[1]
+    if k.shape[0] != T or tuple(v.shape) != tuple(k.shape) or k.shape[2] != D:
+        raise ValueError("q/k/v token counts or head_dim differ")
+    if k.dtype != q.dtype or v.dtype != q.dtype:
+        raise TypeError("q/k/v dtypes differ")
+    if cu_seqlens.dtype != torch.int32:
+        raise TypeError("cu_seqlens must be int32")
+    cu_seqlens = cu_seqlens.contiguous()
+    out = torch.empty((T, Hq, D), dtype=q.dtype, device=dev)
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    with torch.cuda.device(dev):
+        rc = lib.mi355_prefill_causal(
+            out.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), _stride(q, 0), _stride(k, 0),
+            cu_seqlens.data_ptr(), cu_seqlens.numel() - 1, T, int(max_seqlen), Hq, Hkv, D,
+            float(scale), dtype_code(q), _stream(dev))
+    _lib.check(rc, 'mi355_prefill_causal')
+    return out
+
+
+def sample_argmax(logits: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Row-wise argmax of [B, vocab] logits -> int32 [B] (ties: lowest index; NaN wins)."""
+    dev = require_device(logits)
+    lib = _lib.load()
+    if logits.dim() != 2:
+        raise ValueError("logits must be [batch, vocab]")
+    if logits.stride(1) != 1:
+        logits = logits.contiguous()
+    B, V = logits.shape
+    if out is None:
+        out = torch.empty((B,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.mi355_sample_argmax(out.data_ptr(), logits.data_ptr(), B, V, _stride(logits, 0),
+                                     dtype_code(logits), _stream(dev))
+    _lib.check(rc, 'mi355_sample_argmax')
+    return out
+
+
+def sample_topk_topp(logits: torch.Tensor, temperature: torch.Tensor,
+                     top_p: Optional[torch.Tensor] = None, top_k: Optional[torch.Tensor] = None,
+                     seed: int = 0, offset: int = 0, return_probs: bool = False):
+    """One draw per row after temperature / top-k / top-p filtering -> int32 [B]
+    (and, with return_probs, the renormalised post-filter distribution [B, vocab] fp32)."""
+    dev = require_device(logits, temperature, top_p, top_k)
+    lib = _lib.load()
+    if logits.dim() != 2:
+        raise ValueError("logits must be [batch, vocab]")
+    if logits.stride(1) != 1:
+        logits = logits.contiguous()
+    B, V = logits.shape
+    temperature = temperature.to(torch.float32).contiguous()
+    if top_p is not None:
+        top_p = top_p.to(torch.float32).contiguous()
+    if top_k is not None:
+        top_k = top_k.to(torch.int32).contiguous()
+    out = torch.empty((B,), dtype=torch.int32, device=dev)
+    probs = torch.empty((B, V), dtype=torch.float32, device=dev) if return_probs else None
+    with torch.cuda.device(dev):
+        rc = lib.mi355_sample_topk_topp(
+            out.data_ptr(), logits.data_ptr(), temperature.data_ptr(),
+            top_p.data_ptr() if top_p is not None else None,
+            top_k.data_ptr() if top_k is not None else None,
+            int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), B, V, _stride(logits, 0),
+            dtype_code(logits), probs.data_ptr() if probs is not None else None, _stream(dev))
+    _lib.check(rc, 'mi355_sample_topk_topp')
+    return (out, probs) if return_probs else out
+
+
+def slot_mapping(block_tables: torch.Tensor, starts: torch.Tensor, cu_tokens: torch.Tensor,
+                 total_tokens: int, block_size: int) -> torch.Tensor:
+    """Device slot mapping: for sequence b, tokens at positions starts[b] + i land in
+    out[cu_tokens[b] + i] = block_tables[b][pos // BS] * BS + pos % BS. Returns int64 [total]."""
+    dev = require_device(block_tables, starts, cu_tokens)
+    lib = _lib.load()
+    for t in (block_tables, starts, cu_tokens):
+        if t.dtype != torch.int32:
+            raise TypeError("block_tables, starts and cu_tokens must be int32")
+    block_tables = block_tables.contiguous()
+    out = torch.empty((total_tokens,), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.mi355_slot_mapping(out.data_ptr(), block_tables.data_ptr(),
+                                    starts.contiguous().data_ptr(), cu_tokens.contiguous().data_ptr(),
+                                    block_tables.shape[0], block_tables.shape[1], int(block_size),
+                                    int(total_tokens), _stream(dev))
+    _lib.check(rc, 'mi355_slot_mapping')
+    return out
