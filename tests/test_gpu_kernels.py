@@ -149,7 +149,8 @@ def test_decode_metric_shape_subset_bf16(ops, device):
                                ctx.to(device), S)
     assert torch.equal(out_rev.cpu(), torch.from_numpy(out).to(torch.bfloat16)[rev])
     # property 2: moving a sequence's blocks elsewhere in the pool changes nothing
-    spare = torch.tensor([i for i in range(NB) if i not in set(bt.flatten().tolist())][:S // BS])
+    used = set(bt.flatten().tolist())
+    spare = torch.tensor([i for i in range(NB) if i not in used][:S // BS])
     kc2, vc2, bt2 = kc.clone(), vc.clone(), bt.clone()
     kc2[spare] = kc[bt[3].long()]
     vc2[spare] = vc[bt[3].long()]
