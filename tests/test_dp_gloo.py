@@ -1,0 +1,51 @@
+"""Data-parallel sharding helpers on the CPU: world_size-2 gloo processes."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from mi355_paged import dp
+
+
+def test_shard_bounds_cover_everything():
+    for total in (0, 1, 7, 256, 2048, 2049):
+        for world in (1, 2, 3, 8):
+            spans = [dp.shard_bounds(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1 and sizes == dp.shard_sizes(total, world)
+    assert dp.shard_rows(list(range(10)), 4, 1) == [3, 4, 5]
+    with pytest.raises(ValueError):
+        dp.shard_bounds(4, 2, 2)
+
+
+def test_all_gather_is_identity_without_process_group():
+    ids = torch.tensor([5, 6, 7], dtype=torch.int32)
+    assert dp.all_gather_token_ids(ids) is ids
+
+
+def _worker(rank, world, port, total, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        full = torch.arange(100, 100 + total, dtype=torch.int32)      # what a single-GPU run would produce
+        a, b = dp.shard_bounds(total, world, rank)
+        got = dp.all_gather_token_ids(full[a:b].clone(), total=total)
+        torch.save(got, os.path.join(out_dir, f'r{rank}.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('total', [8, 7, 1])
+def test_all_gather_world2_matches_single_process(tmp_path, total):
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, total, str(tmp_path)), nprocs=2, join=True)
+    want = torch.arange(100, 100 + total, dtype=torch.int32)
+    for r in range(2):
+        assert torch.equal(torch.load(tmp_path / f'r{r}.pt'), want)

@@ -84,3 +84,28 @@ def test_g7_nucleus():
         assert sorted(np.nonzero(kept)[0].tolist()) == sorted(ids)          # kept set exact
         np.testing.assert_allclose(probs[ids], c['kept_probs_sorted'], rtol=1e-5, atol=1e-7)
         assert abs(float(probs.sum()) - 1.0) < 1e-5
+
+
+@pytest.mark.parametrize('case', npz_cases('g2_decode_cases.npz'), ids=lambda c: str(c[0]))
+def test_c_port_against_golden(case):
+    from oracle import c_port
+    m, f = case
+    cache = f['kv_cache'].astype(np.float32)
+    out = c_port.paged_decode(f['query'].astype(np.float32)[None], cache[0], cache[1],
+                              f['block_table'][None], [m['s']])[0]
+    np.testing.assert_allclose(out, f['out'], atol=1e-5, rtol=1e-5)
+
+
+def test_c_port_known_answer_and_batch():
+    from oracle import c_port
+    z = load_npz('g1_decode_known_answer.npz')
+    cache = z['kv_cache']
+    out = c_port.paged_decode(z['query'][None], cache[0], cache[1], z['block_table'][None], [int(z['seq_len'])])
+    np.testing.assert_allclose(out[0], z['out_paged'], atol=1e-5, rtol=0)
+    rng = np.random.default_rng(0)
+    kc = rng.standard_normal((2, 9, 2, 4, 16), dtype=np.float32)
+    q = rng.standard_normal((3, 4, 16), dtype=np.float32)
+    bt = np.array([[1, 5, 0], [2, 3, 4], [8, 7, 6]])
+    ctx = [12, 0, 5]
+    want = orc.paged_decode_batch(q, kc[0], kc[1], bt, ctx, 4)
+    np.testing.assert_allclose(c_port.paged_decode(q, kc[0], kc[1], bt, ctx), want, atol=1e-5, rtol=1e-5)

@@ -1,0 +1,643 @@
+"""Drop-in `mini_vllm` module: the reference engine's public names and signatures
+(05_mini_vllm/mini_vllm.py:32-783) with the attention, KV-write and sampling steps
+running as HIP kernels on MI355X.
+
+    BlockAllocator, Request, ScheduledRequest, Scheduler, Sampler,
+    MiniTransformer, MiniVLLM   (+ the nn building blocks they are made of)
+
+What stays host Python: block allocation, scheduling and slot arithmetic (integer
+logic, reproduced decision for decision -- see the golden scheduler traces in
+tests/).  What stays torch: the dense projections (nn.Linear), RMSNorm, RoPE.
+What runs in libmi355_paged.so: the KV slot write, causal prompt attention, paged
+decode attention through block tables, greedy argmax and temperature/top-p
+sampling.  Host-resident tensors are staged through HIP device 0 per call; there
+is no CPU implementation of those steps.
+
+Attention semantics.  The reference's decode branch reads flat KV slot 0 only and
+its chunked prefill attends within the current chunk only
+(05_mini_vllm/mini_vllm.py:460-481, :437-458).  This engine by default attends
+every token to its true context through the request's block table; constructing
+`MiniVLLM(..., reference_compat=True)` or calling the model without block tables
+reproduces the reference's behaviour for result comparison.
+"""
+from __future__ import annotations
+
+import math
+import time
+from collections import OrderedDict
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from mi355_paged import ops
+
+
+# ---------------------------------------------------------------------------
+# KV block allocator (host integers)
+# ---------------------------------------------------------------------------
+
+class BlockAllocator:
+    """Fixed pool of physical KV blocks with reference counts, an LRU-ordered free
+    list and a hash -> block map for prefix reuse (05_mini_vllm/mini_vllm.py:32-108).
+
+    allocate() takes the least recently freed block; free() appends at the recent
+    end; a block freed with a hash keeps it until the block is handed out again.
+    Out of blocks -> allocate returns None (no exception).
+    """
+
+    def __init__(self, num_blocks: int, block_size: int):
+        self.num_blocks = num_blocks
+        self.block_size = block_size
+        self.ref_count = [0] * num_blocks
+        # block id -> logical time it became free; insertion order is the eviction order
+        self.free_blocks: "OrderedDict[int, float]" = OrderedDict((b, 0.0) for b in range(num_blocks))
+        self.hash_to_block: dict = {}
+        self.block_to_hash: dict = {}
+        self._time = 0
+
+    def _tick(self) -> float:
+        self._time += 1
+        return float(self._time)
+
+    def allocate(self, block_hash: Optional[int] = None) -> Optional[int]:
+        cached = self.hash_to_block.get(block_hash) if block_hash is not None else None
+        if cached is not None:
+            self.ref_count[cached] += 1
+            self.free_blocks.pop(cached, None)   # a cached block may be sitting in the free list
+            return cached
+        if len(self.free_blocks) == 0:
+            return None
+        victim, _ = self.free_blocks.popitem(last=False)
+        stale = self.block_to_hash.pop(victim, None)
+        if stale is not None:
+            self.hash_to_block.pop(stale, None)
+        self.ref_count[victim] = 1
+        return victim
+
+    def free(self, block_id: int):
+        if self.ref_count[block_id] <= 0:
+            return
+        self.ref_count[block_id] -= 1
+        if self.ref_count[block_id] == 0:
+            self.free_blocks[block_id] = self._tick()
+
+    def mark_cached(self, block_id: int, block_hash: int):
+        if block_hash not in self.hash_to_block:
+            self.hash_to_block[block_hash] = block_id
+            self.block_to_hash[block_id] = block_hash
+
+    @property
+    def num_free(self) -> int:
+        return len(self.free_blocks)
+
+
+# ---------------------------------------------------------------------------
+# requests and scheduler (host integers)
+# ---------------------------------------------------------------------------
+
+@dataclass
+class Request:
+    """One generation request and its running state (05_mini_vllm/mini_vllm.py:115-152)."""
+    request_id: str
+    prompt_token_ids: List[int]
+    max_new_tokens: int
+    temperature: float = 1.0
+    top_p: float = 1.0
+
+    output_token_ids: List[int] = field(default_factory=list)
+    num_computed_tokens: int = 0
+    block_table: List[int] = field(default_factory=list)
+    is_finished: bool = False
+    arrival_time: float = field(default_factory=time.time)
+
+    @property
+    def prompt_len(self) -> int:
+        return len(self.prompt_token_ids)
+
+    @property
+    def num_tokens(self) -> int:
+        return len(self.prompt_token_ids) + len(self.output_token_ids)
+
+    @property
+    def is_prefill(self) -> bool:
+        return self.num_computed_tokens < len(self.prompt_token_ids)
+
+    @property
+    def next_tokens_to_compute(self) -> List[int]:
+        if self.is_prefill:
+            return self.prompt_token_ids[self.num_computed_tokens:]
+        return self.output_token_ids[-1:]
+
+
+@dataclass
+class ScheduledRequest:
+    request: Request
+    tokens: List[int]
+    positions: List[int]
+    is_prefill: bool
+    slot_mapping: List[int]
+
+
+class Scheduler:
+    """First-come-first-served continuous batching with optional chunked prefill
+    (05_mini_vllm/mini_vllm.py:164-337).
+
+    Each schedule() call first revisits the running requests in order (a decode
+    request costs one token; a request still in prefill takes the next chunk), then
+    admits waiting requests in arrival order, all under a per-step token budget and
+    a cap on the number of sequences.  Two behaviours of the reference are kept on
+    purpose: a request admitted from the waiting queue with chunking disabled is
+    scheduled whole even when it exceeds the remaining budget, and blocks obtained
+    by a partially successful reservation stay with the request.
+    """
+
+    def __init__(self, max_num_seqs: int, max_num_batched_tokens: int, block_size: int,
+                 allocator: BlockAllocator, enable_chunked_prefill: bool = True):
+        self.max_num_seqs = max_num_seqs
+        self.max_num_batched_tokens = max_num_batched_tokens
+        self.block_size = block_size
+        self.allocator = allocator
+        self.enable_chunked_prefill = enable_chunked_prefill
+        self.waiting: List[Request] = []
+        self.running: List[Request] = []
+        self.finished: List[Request] = []
+
+    def add_request(self, request: Request):
+        self.waiting.append(request)
+
+    def _ensure_blocks(self, req: Request, num_new_tokens: int) -> bool:
+        """Grow req.block_table to cover num_computed_tokens + num_new_tokens."""
+        needed = math.ceil((req.num_computed_tokens + num_new_tokens) / self.block_size)
+        while len(req.block_table) < needed:
+            got = self.allocator.allocate()
+            if got is None:
+                return False
+            req.block_table.append(got)
+        return True
+
+    def _compute_slot_mapping(self, req: Request, tokens: Sequence[int], start_pos: int) -> List[int]:
+        bs = self.block_size
+        table = req.block_table
+        return [table[pos // bs] * bs + pos % bs for pos in range(start_pos, start_pos + len(tokens))]
+
+    def _emit(self, req: Request, tokens: List[int], start: int, prefill: bool) -> ScheduledRequest:
+        return ScheduledRequest(request=req, tokens=tokens,
+                                positions=list(range(start, start + len(tokens))),
+                                is_prefill=prefill,
+                                slot_mapping=self._compute_slot_mapping(req, tokens, start))
+
+    def schedule(self) -> List[ScheduledRequest]:
+        batch: List[ScheduledRequest] = []
+        budget = self.max_num_batched_tokens
+        chunked = self.enable_chunked_prefill
+
+        def room() -> bool:
+            return len(batch) < self.max_num_seqs and budget >= 1
+
+        survivors: List[Request] = []
+        for req in self.running:
+            if req.is_finished:
+                continue
+            survivors.append(req)
+            if req.is_prefill:
+                left = req.prompt_len - req.num_computed_tokens
+                want = min(left, budget) if chunked else left
+                if want <= 0 or not room():
+                    continue
+                want = min(want, budget)          # a running request never exceeds the budget
+                if not self._ensure_blocks(req, want):
+                    continue
+                first = req.num_computed_tokens
+                batch.append(self._emit(req, req.prompt_token_ids[first:first + want], first, True))
+                budget -= want
+            else:
+                if not room() or not self._ensure_blocks(req, 1):
+                    continue
+                last = req.output_token_ids[-1:] or req.prompt_token_ids[-1:]
+                batch.append(self._emit(req, last, req.num_computed_tokens, False))
+                budget -= len(last)
+        self.running = survivors
+
+        still_waiting: List[Request] = []
+        for req in self.waiting:
+            admitted = False
+            if room():
+                want = min(req.prompt_len, budget) if chunked else req.prompt_len
+                if want > 0 and self._ensure_blocks(req, want):
+                    batch.append(self._emit(req, req.prompt_token_ids[:want], 0, True))
+                    budget -= want
+                    self.running.append(req)
+                    admitted = True
+            if not admitted:
+                still_waiting.append(req)
+        self.waiting = still_waiting
+        return batch
+
+    def update(self, scheduled: List[ScheduledRequest], next_token_ids: List[int]):
+        """Advance every scheduled request by the tokens it was fed; a request whose prompt
+        is fully consumed takes the sampled token, and finishes on max_new_tokens or on
+        token id 0 (the demo's end-of-sequence id), returning its blocks."""
+        for item, token in zip(scheduled, next_token_ids):
+            req = item.request
+            req.num_computed_tokens += len(item.tokens)
+            if item.is_prefill and req.is_prefill:
+                continue                              # more prompt chunks to come
+            req.output_token_ids.append(token)
+            if len(req.output_token_ids) >= req.max_new_tokens or token == 0:
+                req.is_finished = True
+                for block in req.block_table:
+                    self.allocator.free(block)
+                self.running = [r for r in self.running if r is not req]
+                self.finished.append(req)
+
+    @property
+    def has_unfinished(self) -> bool:
+        return bool(self.waiting or self.running)
+
+
+# ---------------------------------------------------------------------------
+# per-step attention plan (host) and the kernel-backed attention step
+# ---------------------------------------------------------------------------
+
+@dataclass
+class AttnPlan:
+    """Which kernel serves which token of a flattened step.
+
+    Prompt segments that start at position 0 go through the causal prefill kernel
+    (they only need their own fresh K/V).  Every other token -- decode tokens and
+    later chunks of a chunked prompt -- becomes one row of a paged-decode launch
+    with its own context length and block table.
+    """
+    total_tokens: int
+    causal_index: Optional[torch.Tensor]      # int64 [Tc] token ids served by causal prefill (None = all)
+    cu_seqlens: Optional[torch.Tensor]        # int32 [nseg + 1]
+    causal_tokens: int
+    max_causal_len: int
+    paged_index: Optional[torch.Tensor]       # int64 [R] token ids served by paged decode (None = all)
+    paged_tables: Optional[torch.Tensor]      # int32 [R, max_blocks]
+    paged_context: Optional[torch.Tensor]     # int32 [R]
+    paged_rows: int
+    max_context: int
+
+
+def build_attn_plan(positions: Sequence[int], seq_lens: Sequence[int], is_prefill: Sequence[bool],
+                    block_tables: Optional[Sequence[Sequence[int]]], device,
+                    reference_compat: bool = False) -> AttnPlan:
+    causal_tok: List[int] = []
+    cu = [0]
+    max_len = 0
+    paged_tok: List[int] = []
+    paged_ctx: List[int] = []
+    paged_tab: List[Sequence[int]] = []
+    compat = reference_compat or block_tables is None
+    tok = 0
+    for r, (n, prefill) in enumerate(zip(seq_lens, is_prefill)):
+        n_q = n if prefill else 1
+        start = positions[tok] if n > 0 else 0
+        if prefill and (compat or start == 0):
+            causal_tok.extend(range(tok, tok + n_q))
+            cu.append(cu[-1] + n_q)
+            max_len = max(max_len, n_q)
+        elif compat:
+            # the reference's decode branch: context = flat KV slot 0 only
+            paged_tok.append(tok)
+            paged_ctx.append(1)
+            paged_tab.append((0,))
+        else:
+            table = block_tables[r]
+            for j in range(n_q):
+                paged_tok.append(tok + j)
+                paged_ctx.append(positions[tok + j] + 1)
+                paged_tab.append(table)
+        tok += n_q
+    total = tok
+
+    def idx(lst):
+        if len(lst) == total:
+            return None
+        return torch.tensor(lst, dtype=torch.int64, device=device)
+
+    plan = AttnPlan(total_tokens=total, causal_index=None, cu_seqlens=None, causal_tokens=len(causal_tok),
+                    max_causal_len=max_len, paged_index=None, paged_tables=None, paged_context=None,
+                    paged_rows=len(paged_tok), max_context=max(paged_ctx) if paged_ctx else 0)
+    if causal_tok:
+        plan.causal_index = idx(causal_tok)
+        plan.cu_seqlens = torch.tensor(cu, dtype=torch.int32, device=device)
+    if paged_tok:
+        plan.paged_index = idx(paged_tok)
+        width = max(len(t) for t in paged_tab)
+        rows = [list(t) + [0] * (width - len(t)) for t in paged_tab]
+        plan.paged_tables = torch.tensor(rows, dtype=torch.int32, device=device)
+        plan.paged_context = torch.tensor(paged_ctx, dtype=torch.int32, device=device)
+    return plan
+
+
+def _compute_device(t: torch.Tensor) -> torch.device:
+    if t.is_cuda:
+        return t.device
+    if not torch.cuda.is_available():
+        raise RuntimeError("mini_vllm: a HIP device is required for attention / sampling "
+                           "(no CPU implementation)")
+    return torch.device('cuda', 0)
+
+
+def paged_attention_step(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, k_cache: torch.Tensor,
+                         v_cache: torch.Tensor, slot_mapping: torch.Tensor, plan: AttnPlan,
+                         scale: float) -> torch.Tensor:
+    """KV write + attention for one layer of one step.  q, k, v: [T, H, D]; caches
+    [blocks, block_size, H, D].  Returns [T, H, D] on q's device."""
+    home = q.device
+    dev = _compute_device(k_cache)
+    staged = not k_cache.is_cuda
+    kc = k_cache.to(dev) if staged else k_cache
+    vc = v_cache.to(dev) if staged else v_cache
+    q, k, v = q.to(dev), k.to(device=dev, dtype=kc.dtype), v.to(device=dev, dtype=kc.dtype)
+    ops.kv_write_slots(kc, vc, k, v, slot_mapping.to(dev), layout='NSHD')
+    if staged:
+        k_cache.copy_(kc)
+        v_cache.copy_(vc)
+    out = None
+    if plan.causal_tokens:
+        sel = plan.causal_index
+        part = ops.prefill_causal(q if sel is None else q[sel], k if sel is None else k[sel],
+                                  v if sel is None else v[sel], plan.cu_seqlens, plan.max_causal_len, scale)
+        if sel is None:
+            out = part
+        else:
+            out = torch.empty_like(q)
+            out[sel] = part
+    if plan.paged_rows:
+        sel = plan.paged_index
+        part = ops.paged_decode(q if sel is None else q[sel], kc, vc, plan.paged_tables,
+                                plan.paged_context, plan.max_context, layout='NSHD', scale=scale)
+        if sel is None:
+            out = part
+        else:
+            if out is None:
+                out = torch.empty_like(q)
+            out[sel] = part
+    return out.to(home)
+
+
+# ---------------------------------------------------------------------------
+# model
+# ---------------------------------------------------------------------------
+
+class RMSNorm(nn.Module):
+    def __init__(self, dim: int, eps: float = 1e-6):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.eps = eps
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        rms = (x * x).mean(dim=-1, keepdim=True).add(self.eps).sqrt()
+        return self.weight * (x / rms)
+
+
+def rotate_half(x: torch.Tensor) -> torch.Tensor:
+    lo, hi = x.chunk(2, dim=-1)
+    return torch.cat((-hi, lo), dim=-1)
+
+
+class RotaryEmbedding(nn.Module):
+    """cos/sin tables [max_len, dim] for rotate-half RoPE, base 10000
+    (05_mini_vllm/mini_vllm.py:360-374)."""
+
+    def __init__(self, dim: int, max_len: int = 8192, base: float = 10000.0):
+        super().__init__()
+        inv_freq = 1.0 / (base ** (torch.arange(0, dim, 2).float() / dim))
+        angles = torch.outer(torch.arange(max_len).float(), inv_freq)
+        table = torch.cat([angles, angles], dim=-1)
+        self.register_buffer('inv_freq', inv_freq)
+        self.register_buffer('cos_cached', table.cos())
+        self.register_buffer('sin_cached', table.sin())
+
+    def forward(self, positions: torch.Tensor):
+        return self.cos_cached[positions], self.sin_cached[positions]
+
+
+class SelfAttention(nn.Module):
+    """Multi-head attention over a paged KV cache (05_mini_vllm/mini_vllm.py:377-487).
+    The projections and RoPE are torch ops; the KV write and both attention branches
+    are kernel launches driven by an AttnPlan."""
+
+    def __init__(self, hidden_size: int, num_heads: int, head_dim: int):
+        super().__init__()
+        self.num_heads = num_heads
+        self.head_dim = head_dim
+        self.scale = head_dim ** -0.5
+        self.qkv = nn.Linear(hidden_size, 3 * num_heads * head_dim, bias=False)
+        self.out_proj = nn.Linear(num_heads * head_dim, hidden_size, bias=False)
+        self.rope = RotaryEmbedding(head_dim)
+
+    def forward(self, x, positions, kv_cache, slot_mapping, seq_lens, is_prefill, plan: Optional[AttnPlan] = None):
+        T, H, D = x.shape[0], self.num_heads, self.head_dim
+        if plan is None:   # called the reference's way: no block tables -> reference semantics
+            plan = build_attn_plan(positions.tolist(), seq_lens, is_prefill, None, _compute_device(kv_cache[0]))
+        q, k, v = (t.reshape(T, H, D) for t in self.qkv(x).chunk(3, dim=-1))
+        cos, sin = self.rope(positions)
+        cos, sin = cos.unsqueeze(1), sin.unsqueeze(1)
+        q = q * cos + rotate_half(q) * sin
+        k = k * cos + rotate_half(k) * sin
+        k_cache, v_cache = kv_cache
+        attn = paged_attention_step(q, k, v, k_cache, v_cache, slot_mapping, plan, self.scale)
+        return self.out_proj(attn.reshape(plan.total_tokens, H * D).to(x.dtype))
+
+
+class FFN(nn.Module):
+    """SwiGLU feed-forward."""
+
+    def __init__(self, hidden_size: int, intermediate_size: int):
+        super().__init__()
+        self.gate = nn.Linear(hidden_size, intermediate_size, bias=False)
+        self.up = nn.Linear(hidden_size, intermediate_size, bias=False)
+        self.down = nn.Linear(intermediate_size, hidden_size, bias=False)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.down(F.silu(self.gate(x)) * self.up(x))
+
+
+class TransformerLayer(nn.Module):
+    def __init__(self, hidden_size: int, num_heads: int, intermediate_size: int):
+        super().__init__()
+        self.attn = SelfAttention(hidden_size, num_heads, hidden_size // num_heads)
+        self.ffn = FFN(hidden_size, intermediate_size)
+        self.norm1 = RMSNorm(hidden_size)
+        self.norm2 = RMSNorm(hidden_size)
+
+    def forward(self, x, positions, kv_cache, slot_mapping, seq_lens, is_prefill, plan=None):
+        x = x + self.attn(self.norm1(x), positions, kv_cache, slot_mapping, seq_lens, is_prefill, plan)
+        return x + self.ffn(self.norm2(x))
+
+
+class MiniTransformer(nn.Module):
+    """Small pre-norm transformer that owns its paged KV buffers
+    k_cache / v_cache [layers, blocks, block_size, heads, head_dim]
+    (05_mini_vllm/mini_vllm.py:517-585)."""
+
+    def __init__(self, vocab_size: int, hidden_size: int, num_layers: int, num_heads: int,
+                 intermediate_size: int, num_kv_blocks: int, block_size: int):
+        super().__init__()
+        self.hidden_size = hidden_size
+        self.num_layers = num_layers
+        self.block_size = block_size
+        head_dim = hidden_size // num_heads
+        self.embedding = nn.Embedding(vocab_size, hidden_size)
+        self.layers = nn.ModuleList(
+            TransformerLayer(hidden_size, num_heads, intermediate_size) for _ in range(num_layers))
+        self.norm = RMSNorm(hidden_size)
+        self.lm_head = nn.Linear(hidden_size, vocab_size, bias=False)
+        cache_shape = (num_layers, num_kv_blocks, block_size, num_heads, head_dim)
+        self.register_buffer('k_cache', torch.zeros(cache_shape))
+        self.register_buffer('v_cache', torch.zeros(cache_shape))
+
+    def forward(self, token_ids: torch.Tensor, positions: torch.Tensor, slot_mapping: torch.Tensor,
+                seq_lens: List[int], is_prefill: List[bool],
+                block_tables: Optional[Sequence[Sequence[int]]] = None,
+                positions_host: Optional[Sequence[int]] = None,
+                reference_compat: bool = False) -> torch.Tensor:
+        """Logits [batch, vocab] for the last token of every request in the flattened step.
+
+        The five leading arguments are the reference's; block_tables (one list of physical
+        block ids per request) enables attention over the true paged context, positions_host
+        is an optional host copy of `positions` that saves a device read-back."""
+        home = self.embedding.weight.device
+        token_ids, positions, slot_mapping = (t.to(home) for t in (token_ids, positions, slot_mapping))
+        if positions_host is None:
+            positions_host = positions.tolist()
+        plan = build_attn_plan(positions_host, seq_lens, is_prefill, block_tables,
+                               _compute_device(self.k_cache), reference_compat)
+        x = self.embedding(token_ids)
+        for i, layer in enumerate(self.layers):
+            x = layer(x, positions, (self.k_cache[i], self.v_cache[i]), slot_mapping, seq_lens, is_prefill, plan)
+        x = self.norm(x)
+        last, offset = [], 0
+        for n in seq_lens:
+            offset += n
+            last.append(offset - 1)
+        return self.lm_head(x[last])
+
+
+# ---------------------------------------------------------------------------
+# sampler
+# ---------------------------------------------------------------------------
+
+class Sampler:
+    """temperature == 0 -> argmax; otherwise softmax(logits / T), optional nucleus
+    filtering (top_p < 1) and one multinomial draw (05_mini_vllm/mini_vllm.py:592-634).
+    A request may also carry an integer `top_k` attribute (> 0) -- not part of the
+    reference -- which keeps only the k most probable tokens.
+
+    The whole batch is sampled by at most two kernel launches and read back with a
+    single device-to-host copy.  Random draws come from a counter-based generator
+    seeded from torch's global CPU generator, so torch.manual_seed() makes runs
+    repeatable; the draws are not the same numbers torch.multinomial would produce.
+    """
+
+    @staticmethod
+    def sample(logits: torch.Tensor, requests: List[Request]) -> List[int]:
+        n = len(requests)
+        if n == 0:
+            return []
+        dev = _compute_device(logits)
+        rows = logits[:n].to(dev)
+        temps = [float(r.temperature) for r in requests]
+        greedy = [t == 0.0 for t in temps]
+        picked = None
+        if any(greedy):
+            picked = ops.sample_argmax(rows)
+        if not all(greedy):
+            top_p = [float(r.top_p) for r in requests]
+            top_k = [int(getattr(r, 'top_k', 0) or 0) for r in requests]
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            drawn = ops.sample_topk_topp(
+                rows, torch.tensor([t if t != 0.0 else 1.0 for t in temps], dtype=torch.float32, device=dev),
+                torch.tensor(top_p, dtype=torch.float32, device=dev) if any(p < 1.0 for p in top_p) else None,
+                torch.tensor(top_k, dtype=torch.int32, device=dev) if any(k > 0 for k in top_k) else None,
+                seed=seed)
+            if picked is None:
+                picked = drawn
+            else:
+                picked = torch.where(torch.tensor(greedy, device=dev), picked, drawn)
+        return [int(t) for t in picked.tolist()]
+
+
+# ---------------------------------------------------------------------------
+# engine
+# ---------------------------------------------------------------------------
+
+class MiniVLLM:
+    """schedule -> flatten -> model forward -> sample -> update
+    (05_mini_vllm/mini_vllm.py:641-783).  Extra keyword arguments, all optional:
+    reference_compat (see module docstring) and dtype (parameter / KV cache dtype)."""
+
+    def __init__(self, vocab_size: int = 1000, hidden_size: int = 128, num_layers: int = 2,
+                 num_heads: int = 4, intermediate_size: int = 512, num_kv_blocks: int = 256,
+                 block_size: int = 16, max_num_seqs: int = 8, max_num_batched_tokens: int = 1024,
+                 enable_chunked_prefill: bool = True, device: str = 'cpu',
+                 reference_compat: bool = False, dtype: Optional[torch.dtype] = None):
+        self.device = torch.device(device)
+        self.reference_compat = reference_compat
+        self.allocator = BlockAllocator(num_kv_blocks, block_size)
+        self.scheduler = Scheduler(max_num_seqs=max_num_seqs,
+                                   max_num_batched_tokens=max_num_batched_tokens,
+                                   block_size=block_size, allocator=self.allocator,
+                                   enable_chunked_prefill=enable_chunked_prefill)
+        self.model = MiniTransformer(vocab_size=vocab_size, hidden_size=hidden_size,
+                                     num_layers=num_layers, num_heads=num_heads,
+                                     intermediate_size=intermediate_size,
+                                     num_kv_blocks=num_kv_blocks, block_size=block_size).to(self.device)
+        if dtype is not None:
+            self.model = self.model.to(dtype)
+        self.sampler = Sampler()
+        self._req_counter = 0
+
+    def add_request(self, prompt_token_ids: List[int], max_new_tokens: int = 20,
+                    temperature: float = 1.0, top_p: float = 1.0) -> str:
+        req_id = f"req-{self._req_counter}"
+        self._req_counter += 1
+        self.scheduler.add_request(Request(request_id=req_id, prompt_token_ids=prompt_token_ids,
+                                           max_new_tokens=max_new_tokens, temperature=temperature,
+                                           top_p=top_p))
+        return req_id
+
+    def step(self):
+        """One engine step; returns [(request_id, new_token)] for every request that
+        produced a token (decode steps and the final chunk of a prompt)."""
+        scheduled = self.scheduler.schedule()
+        if not scheduled:
+            return []
+        tokens: List[int] = []
+        positions: List[int] = []
+        slots: List[int] = []
+        for item in scheduled:
+            tokens += item.tokens
+            positions += item.positions
+            slots += item.slot_mapping
+        seq_lens = [len(item.tokens) for item in scheduled]
+        prefill_flags = [item.is_prefill for item in scheduled]
+        requests = [item.request for item in scheduled]
+
+        as_long = dict(dtype=torch.long, device=self.device)
+        with torch.no_grad():
+            logits = self.model(torch.tensor(tokens, **as_long), torch.tensor(positions, **as_long),
+                                torch.tensor(slots, **as_long), seq_lens, prefill_flags,
+                                block_tables=[r.block_table for r in requests],
+                                positions_host=positions, reference_compat=self.reference_compat)
+        next_tokens = self.sampler.sample(logits, requests)
+        self.scheduler.update(scheduled, next_tokens)
+        return [(item.request.request_id, tok) for item, tok in zip(scheduled, next_tokens)
+                if not (item.is_prefill and item.request.is_prefill)]
+
+    def generate(self, prompts: List[List[int]], max_new_tokens: int = 20):
+        """Run the given prompts to completion -> {request_id: generated token ids}."""
+        ids = [self.add_request(p, max_new_tokens=max_new_tokens) for p in prompts]
+        outputs = {rid: [] for rid in ids}
+        while self.scheduler.has_unfinished:
+            for rid, tok in self.step():
+                if rid in outputs:
+                    outputs[rid].append(tok)
+        return outputs
