@@ -71,7 +71,7 @@ def build_inputs(cfg, device, seed, sets=2):
     return dict(pools=pools, q=q, k_new=k_new, v_new=v_new, ctx=ctx, logits=logits, slots=slots)
 
 
-def cpu_baseline(cfg, inp, budget_s=12.0, max_seqs=32):
+def cpu_baseline(cfg, inp, budget_s=12.0, max_seqs=256):
     """Reference-shaped CPU decode on a sample of the benchmark's own sequences (fp32, as the
     reference runs it).  Returns the JSON object for the bench line."""
     from oracle import loop_form, paged_oracle

@@ -317,7 +317,10 @@ int env_int(const char* name, int dflt) {
 
 int elems_per_lane(int dtype) { return dtype == MI355_F32 ? 4 : 8; }
 
-constexpr int kU = 4;  // 16-byte loads of K (and of V) per lane per pipeline step
+#ifndef MI355_DECODE_U
+#define MI355_DECODE_U 4
+#endif
+constexpr int kU = MI355_DECODE_U;  // 16-byte loads of K (and of V) per lane per pipeline step
 
 // Launch geometry for a problem shape.  Deterministic in its arguments (plus the
 // MI355_PAGED_TARGET_WGS tuning variable), so the workspace query and the launch agree.
@@ -343,7 +346,7 @@ int make_plan(int B, int Hq, int Hkv, int D, int block_size, int max_context, in
   const int quantum = pl.sub * ts;  // tokens one workgroup consumes per pipeline step
   const int ctx = max_context > 0 ? max_context : 1;
   const int64_t base_wgs = (int64_t)B * pl.hgroups * pl.qchunks;
-  const int target = env_int("MI355_PAGED_TARGET_WGS", 1024);
+  const int target = env_int("MI355_PAGED_TARGET_WGS", 256);  // one workgroup per CU before splitting tokens
   int64_t want = ceil_div64(target, base_wgs);
   const int64_t most = ctx / (2 * quantum) > 0 ? ctx / (2 * quantum) : 1;  // >= 2 steps per wave
   if (want > most) want = most;

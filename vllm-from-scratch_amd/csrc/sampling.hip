@@ -49,7 +49,7 @@ __device__ __forceinline__ bool cand_better(float av, int ai, float bv, int bi) 
 }
 
 template <class Tag>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(1024)
 argmax_kernel(int32_t* out, const typename Tag::elem_t* logits, int vocab, int64_t row_stride, int vec_ok) {
   constexpr int EPL = Tag::kEPL;
   __shared__ float s_v[kMaxWaves];
@@ -67,12 +67,27 @@ argmax_kernel(int32_t* out, const typename Tag::elem_t* logits, int vocab, int64
       best_i = idx;
     }
   };
+  // 16-byte pieces, four independent loads in flight per thread; pieces are visited in
+  // increasing index order so "first occurrence" stays well defined per thread.
   const int nvec = vec_ok ? vocab / EPL : 0;
-  for (int c = tid; c < nvec; c += nt) {
-    float f[EPL];
-    Tag::unpack(*reinterpret_cast<const u32x4*>(row + (int64_t)c * EPL), f);
+  constexpr int kFly = 4;
+  for (int c0 = tid; c0 < nvec; c0 += nt * kFly) {
+    u32x4 raw[kFly];
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) visit(f[e], c * EPL + e);
+    for (int j = 0; j < kFly; ++j) {
+      const int c = min(c0 + j * nt, nvec - 1);
+      raw[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(row + (int64_t)c * EPL));
+    }
+#pragma unroll
+    for (int j = 0; j < kFly; ++j) {
+      const int c = c0 + j * nt;
+      if (c < nvec) {
+        float f[EPL];
+        Tag::unpack(raw[j], f);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) visit(f[e], c * EPL + e);
+      }
+    }
   }
   for (int idx = nvec * EPL + tid; idx < vocab; idx += nt) visit(Tag::to_float(row[idx]), idx);
 
@@ -352,7 +367,7 @@ extern "C" int mi355_sample_argmax(int32_t* out_ids, const void* logits, int32_t
   if (!out_ids || !logits) return fail(MI355_EINVAL, "sample_argmax: null pointer");
   if (B < 0 || vocab <= 0 || row_stride < vocab) return fail(MI355_EINVAL, "sample_argmax: bad shape");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int threads = vocab >= 8192 ? 512 : vocab >= 1024 ? 256 : 64;
+  const int threads = vocab >= 16384 ? 1024 : vocab >= 4096 ? 512 : vocab >= 1024 ? 256 : 64;
   const int ebytes = dtype == MI355_F32 ? 4 : 2;
   const int vec_ok = (((uintptr_t)logits & 15) == 0) && ((row_stride * ebytes) % 16 == 0);
   switch (dtype) {

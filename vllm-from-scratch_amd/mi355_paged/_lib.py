@@ -10,7 +10,8 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libmi355_paged.so')
+# MI355_PAGED_LIB selects another build of the same library (kernel tuning experiments)
+LIB_PATH = os.environ.get('MI355_PAGED_LIB') or os.path.join(_HERE, 'libmi355_paged.so')
 ABI_VERSION = 1
 
 # name -> (restype, argtypes); mirrors include/mi355_paged.h one to one
