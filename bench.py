@@ -123,12 +123,23 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device")
-    device = torch.device('cuda', local_rank)
+    # BENCH_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
+    backend = os.environ.get('BENCH_DIST_BACKEND', 'nccl')
+    device = torch.device('cuda', local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group('nccl', device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
 
+    trace = (lambda m: print(f"[rank {rank}] {m}", file=sys.stderr, flush=True)) \
+        if os.environ.get('BENCH_TRACE') else (lambda m: None)
+    if os.environ.get('BENCH_TRACE'):
+        import faulthandler
+        faulthandler.dump_traceback_later(40, exit=False, file=sys.stderr)
+    trace('process group up')
     from mi355_paged import dp, ops
     cfg = CONFIGS[args.config]
     B, S, H, D, BS = cfg['B'], cfg['S'], cfg['H'], cfg['D'], cfg['BS']
@@ -156,16 +167,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    trace('inputs built')
     for i in range(args.warmup):
         step(i, False)
+    trace('warmup issued')
     barrier()
+    trace('timed region')
     t0 = time.perf_counter()
     for i in range(args.steps):
         gathered = step(i, True)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert gathered.numel() == B * world

@@ -44,6 +44,9 @@ def all_gather_token_ids(local_ids: torch.Tensor, total: Optional[int] = None,
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local_ids
     world = dist.get_world_size(group)
+    if local_ids.is_cuda and dist.get_backend(group) == 'gloo':
+        # gloo moves host memory only: stage through the CPU (CPU tests and rehearsals)
+        return all_gather_token_ids(local_ids.cpu(), total, group).to(local_ids.device)
     n_local = local_ids.numel()
     if total is None:
         total = n_local * world
