@@ -335,3 +335,65 @@ def test_engine_chunked_prefill_equals_unchunked(mv, device):
         logs[name] = (cap[-1], steps)
     assert logs['whole'][1] == 1 and logs['chunked'][1] == 3
     assert torch.allclose(logs['whole'][0], logs['chunked'][0], atol=1e-4)
+
+
+# ------------------------------------------------------------------ mixed chunked-prefill + decode batch, batch=128
+def test_engine_mixed_batch_128_attention_parity(mv, device, monkeypatch):
+    """BASELINE config 3: 128 concurrent sequences through MiniVLLM with chunked prefill, so that
+    steps mix first chunks, later chunks and decode rows.  Every step's layer-0 attention output
+    is recomputed on the CPU (oracle over the true paged context read back from the cache) for a
+    sample of tokens; fp32 engine, atol 2e-5."""
+    from oracle import paged_oracle as orc
+    torch.manual_seed(1)
+    H, D, BS = 8, 64, 16
+    eng = mv.MiniVLLM(vocab_size=500, hidden_size=H * D, num_layers=2, num_heads=H, intermediate_size=256,
+                      num_kv_blocks=1200, block_size=BS, max_num_seqs=128, max_num_batched_tokens=1024,
+                      enable_chunked_prefill=True, device='cuda')
+    rng = np.random.default_rng(3)
+    prompts = [[int(t) for t in rng.integers(1, 500, size=int(rng.integers(4, 120)))] for _ in range(128)]
+    for p in prompts:
+        eng.add_request(p, max_new_tokens=4, temperature=0.0)
+
+    real = mv.paged_attention_step
+    checked = {'tokens': 0, 'steps': 0, 'kinds': set()}
+
+    def spy(q, k, v, k_cache, v_cache, slot_mapping, plan, scale):
+        out = real(q, k, v, k_cache, v_cache, slot_mapping, plan, scale)
+        if k_cache.data_ptr() != eng.model.k_cache[0].data_ptr():
+            return out                                              # only layer 0 is audited
+        kc = k_cache.permute(0, 2, 1, 3).float().cpu().numpy()      # -> [NB, H, BS, D]
+        vc = v_cache.permute(0, 2, 1, 3).float().cpu().numpy()
+        qn, on = q.float().cpu().numpy(), out.float().cpu().numpy()
+        sched = spy.scheduled
+        tok = 0
+        for item in sched:
+            table = item.request.block_table
+            picks = {0, len(item.tokens) - 1, len(item.tokens) // 2}
+            for j in picks:
+                ctx = item.positions[j] + 1
+                want = orc.paged_decode(qn[tok + j], kc, vc, table, ctx, BS, scale=scale)
+                np.testing.assert_allclose(on[tok + j], want, atol=2e-5, rtol=1e-4)
+                checked['tokens'] += 1
+            kind = 'decode' if not item.is_prefill else ('first' if item.positions[0] == 0 else 'later')
+            checked['kinds'].add(kind)
+            tok += len(item.tokens)
+        checked['steps'] += 1
+        return out
+
+    monkeypatch.setattr(mv, 'paged_attention_step', spy)
+    real_schedule = eng.scheduler.schedule
+
+    def schedule_and_remember():
+        spy.scheduled = real_schedule()
+        return spy.scheduled
+
+    eng.scheduler.schedule = schedule_and_remember
+    steps = 0
+    while eng.scheduler.has_unfinished and steps < 40:
+        eng.step()
+        steps += 1
+    assert not eng.scheduler.has_unfinished
+    assert checked['kinds'] == {'decode', 'first', 'later'}
+    assert checked['tokens'] > 500 and checked['steps'] == steps
+    assert max(len(s) for s in [r.output_token_ids for r in eng.scheduler.finished]) == 4
+    assert eng.allocator.num_free == 1200
