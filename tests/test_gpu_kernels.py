@@ -228,6 +228,55 @@ def test_prefill_varlen_packed(ops, device, dtype):
                                **(F32_TOL if dtype == torch.float32 else LOWP_TOL))
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape', [
+    # lens, Hq, Hkv, D
+    ([128], 8, 8, 64), ([129, 1, 63, 64, 65], 8, 8, 64), ([700], 4, 2, 64), ([300, 257], 8, 1, 128),
+    ([33, 500, 2], 2, 2, 128),
+])
+def test_prefill_matrix_core_kernel(ops, device, shape, dtype):
+    """The MFMA prompt kernel (16-bit, head_dim 64/128) against the float64 oracle, and
+    against the VALU kernel it replaces (same inputs, MI355_PREFILL_VALU=1)."""
+    import os
+    lens, Hq, Hkv, D = shape
+    rng = np.random.default_rng(sum(lens) + D)
+    T = sum(lens)
+    q = torch.from_numpy(rng.standard_normal((T, Hq, D), dtype=np.float32)).to(dtype)
+    k = torch.from_numpy(rng.standard_normal((T, Hkv, D), dtype=np.float32)).to(dtype)
+    v = torch.from_numpy(rng.standard_normal((T, Hkv, D), dtype=np.float32)).to(dtype)
+    # a dominant late key in the first sequence forces the running-max rescale of O
+    if lens[0] > 100:
+        k[90, :, :] = (q[95, ::Hq // Hkv, :].float() * 3).to(dtype)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    want = orc.varlen_causal_attention(q.float().numpy(), k.float().numpy(), v.float().numpy(), cu,
+                                       dtype=np.float64)
+    args = (q.to(device), k.to(device), v.to(device), torch.from_numpy(cu).to(device), max(lens))
+    out = ops.prefill_causal(*args)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.float().cpu().numpy(), want, **LOWP_TOL)
+    os.environ['MI355_PREFILL_VALU'] = '1'
+    try:
+        ref = ops.prefill_causal(*args)
+        torch.cuda.synchronize()
+    finally:
+        del os.environ['MI355_PREFILL_VALU']
+    np.testing.assert_allclose(ref.float().cpu().numpy(), want, **LOWP_TOL)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.float().cpu().numpy(), atol=2e-2, rtol=3e-2)
+
+
+def test_prefill_strided_qkv_views(ops, device):
+    """q/k/v as views into one fused projection output, the way the engine passes them."""
+    rng = np.random.default_rng(2)
+    T, H, D = 150, 8, 64
+    qkv = torch.from_numpy(rng.standard_normal((T, 3 * H * D), dtype=np.float32)).to(torch.bfloat16).to(device)
+    q, k, v = (t.reshape(T, H, D) for t in qkv.chunk(3, dim=-1))
+    cu = torch.tensor([0, 100, 150], dtype=torch.int32, device=device)
+    out = ops.prefill_causal(q, k, v, cu, 100)
+    want = orc.varlen_causal_attention(q.float().cpu().numpy(), k.float().cpu().numpy(), v.float().cpu().numpy(),
+                                       [0, 100, 150], dtype=np.float64)
+    np.testing.assert_allclose(out.float().cpu().numpy(), want, **LOWP_TOL)
+
+
 def test_slot_mapping_device(ops, device):
     rng = np.random.default_rng(21)
     B, max_blocks, BS = 6, 12, 8

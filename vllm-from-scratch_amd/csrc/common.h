@@ -21,6 +21,12 @@ int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 // Returns 0 or records + returns the pending hipError_t of the last launch.
 int check_launch(const char* what);
 
+// Matrix-core causal prefill (prefill_mfma.hip): covers 16-bit dtypes at head_dim 64 / 128.
+bool prefill_mfma_supported(int dtype, int D);
+int prefill_mfma_launch(void* out, const void* q, const void* k, const void* v, int64_t q_stride_tok,
+                        int64_t kv_stride_tok, const int32_t* cu_seqlens, int nseq, int total_tokens,
+                        int max_seqlen, int Hq, int Hkv, int D, float scale, int dtype, hipStream_t stream);
+
 static inline int ilog2_exact(int v) {  // log2(v) if v is a power of two, else -1
   if (v <= 0 || (v & (v - 1))) return -1;
   int s = 0;

@@ -496,8 +496,6 @@ extern "C" int mi355_prefill_causal(void* out, const void* q, const void* k, con
                                     int64_t q_stride_tok, int64_t kv_stride_tok, const int32_t* cu_seqlens,
                                     int32_t nseq, int32_t total_tokens, int32_t max_seqlen, int32_t Hq,
                                     int32_t Hkv, int32_t D, float scale, int32_t dtype, void* stream) {
-  // Runs the decode kernel in causal mode: every query token is one row whose
-  // context is the packed k/v rows of its own prompt up to and including itself.
   if (total_tokens == 0 || nseq == 0) return 0;
   if (!out || !q || !k || !v || !cu_seqlens) return fail(MI355_EINVAL, "prefill_causal: null pointer");
   if (total_tokens < 0 || nseq < 0 || max_seqlen <= 0) return fail(MI355_EINVAL, "prefill_causal: bad sizes");
@@ -509,6 +507,12 @@ extern "C" int mi355_prefill_causal(void* out, const void* q, const void* k, con
     return fail(MI355_EINVAL, "prefill_causal: strides must keep head rows 16-byte aligned");
   if (((uintptr_t)out | (uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15)
     return fail(MI355_EINVAL, "prefill_causal: tensors must be 16-byte aligned");
+  // 16-bit inputs at head_dim 64/128 go to the matrix-core kernel; everything else (fp32,
+  // other head dims) runs the VALU decode kernel in causal mode below.
+  // MI355_PREFILL_VALU=1 forces the latter (A/B measurements).
+  if (prefill_mfma_supported(dtype, D) && !env_int("MI355_PREFILL_VALU", 0))
+    return prefill_mfma_launch(out, q, k, v, q_stride_tok, kv_stride_tok, cu_seqlens, nseq, total_tokens,
+                               max_seqlen, Hq, Hkv, D, scale, dtype, static_cast<hipStream_t>(stream));
   DecodeParams p;
   p.out = out;
   p.q = q;

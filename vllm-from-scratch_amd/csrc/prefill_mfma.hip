@@ -1,0 +1,281 @@
+// Causal prompt attention on the matrix cores (bf16 / fp16, head_dim 64 or 128).
+//
+// The prompt's QK^T and PV products are real dense contractions (Tq x Tk x D per
+// head), so unlike decode they belong on MFMA.  Flash-attention structure:
+//
+//   workgroup = 4 waves = 128 consecutive query rows of one (sequence, query head);
+//   wave      = 32 query rows; K/V are walked in 64-key tiles shared by the 4 waves
+//               through LDS (register-staged: the next tile's global loads are issued
+//               before the current tile is reduced).
+//   S^T = K . Q^T  with v_mfma_f32_32x32x16: the 32x32 result has the QUERY on the lane
+//               (column) and 16 keys in the lane's registers, so the softmax row
+//               statistics are lane-local plus one exchange with lane^32, and the
+//               accumulator registers, converted to 16-bit in place, are already the
+//               B operand of the next product (no LDS round trip for P).
+//   O^T += V^T . P^T: the A operand V^T comes from a row-major V tile in LDS through
+//               ds_read_b64_tr_b16 (transposing read).
+//   O^T keeps the query on the lane too, so the online-softmax rescale of O is a
+//   per-lane scalar multiply.
+//
+// Numerics: fp32 scores / statistics / accumulation; P is rounded to the 16-bit
+// input type before the PV product (as every flash-attention kernel does).
+#include "common.h"
+
+namespace mi355 {
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kQW = 32;              // query rows per wave
+constexpr int kWaves = 4;
+constexpr int kQT = kQW * kWaves;    // query rows per workgroup
+constexpr int kKT = 64;              // keys per tile
+
+struct PrefillParams {
+  void* out;
+  const void* q;
+  const void* k;
+  const void* v;
+  const int32_t* cu;
+  int64_t q_stride_tok, kv_stride_tok;
+  int nseq, n_qt_max, Hq, Hkv, total_tokens;
+  float scale_log2e;
+};
+
+template <class Tag>
+struct Mma;
+template <>
+struct Mma<BF16> {
+  static __device__ __forceinline__ f32x16 run(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b),
+                                                   c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    return BF16::round1(lo) | (BF16::round1(hi) << 16);
+  }
+};
+template <>
+struct Mma<F16> {
+  static __device__ __forceinline__ f32x16 run(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c,
+                                                  0, 0, 0);
+  }
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    f16x2_t h;
+    h[0] = (_Float16)lo;
+    h[1] = (_Float16)hi;
+    return __builtin_bit_cast(uint32_t, h);
+  }
+};
+
+template <class Tag, int D>
+__global__ void __launch_bounds__(kWaves * kWave) prefill_mfma_kernel(const PrefillParams p) {
+  constexpr int KS = D / 16;          // k-steps of the S^T product (over head_dim)
+  constexpr int DT = D / 32;          // 32-row tiles of O^T (over head_dim)
+  constexpr int ROWB = D * 2;         // bytes per K / V row in LDS
+  constexpr int CPR = D / 8;          // 16-byte chunks per row
+  constexpr int LOADS = kKT * CPR / (kWaves * kWave);  // 16-byte chunks per thread per tile (K, and again V)
+  __shared__ __attribute__((aligned(16))) unsigned char sK[kKT * ROWB];
+  __shared__ __attribute__((aligned(16))) unsigned char sV[kKT * ROWB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  int bid = blockIdx.x;
+  const int hq = bid % p.Hq;
+  bid /= p.Hq;
+  const int qt = p.n_qt_max - 1 - (bid % p.n_qt_max);   // long (late) tiles are issued first
+  const int seq = bid / p.n_qt_max;
+  const int seq_start = p.cu[seq];
+  const int len = p.cu[seq + 1] - seq_start;
+  const int q0 = qt * kQT;
+  if (q0 >= len) return;
+  const int kvh = hq / (p.Hq / p.Hkv);
+  const int qw0 = q0 + wave * kQW;                      // first query row of this wave
+  const int my_q = qw0 + c;                             // this lane's query row (may be >= len)
+
+  // Q fragments (B operand of S^T = K.Q^T): lane (c,h), k-step s holds Q[c][16s + 8h .. +8).
+  u32x4 qf[KS];
+  {
+    const int row = seq_start + min(my_q, len - 1);
+    const char* src = static_cast<const char*>(p.q) + ((int64_t)row * p.q_stride_tok + (int64_t)hq * D) * 2;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qf[s] = *reinterpret_cast<const u32x4*>(src + (16 * s + 8 * h) * 2);
+  }
+
+  f32x16 o[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  float m_run = -1.0e30f, l_run = 0.f;
+
+  const int kv_end = min(len, q0 + kQT);                // causal: no key past the tile's last query
+  const int ntiles = (kv_end + kKT - 1) / kKT;
+  const char* kbase = static_cast<const char*>(p.k);
+  const char* vbase = static_cast<const char*>(p.v);
+
+  u32x4 kreg[LOADS], vreg[LOADS];
+  auto issue_loads = [&](int tile) {
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+      const int ch = tid + i * (kWaves * kWave);
+      const int key = ch / CPR, dc = ch % CPR;
+      const int row = seq_start + min(tile * kKT + key, len - 1);   // rows past the end are masked below
+      const int64_t off = ((int64_t)row * p.kv_stride_tok + (int64_t)kvh * D + dc * 8) * 2;
+      kreg[i] = *reinterpret_cast<const u32x4*>(kbase + off);
+      vreg[i] = *reinterpret_cast<const u32x4*>(vbase + off);
+    }
+  };
+  auto write_lds = [&]() {
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+      const int ch = tid + i * (kWaves * kWave);
+      const int key = ch / CPR, dc = ch % CPR;
+      *reinterpret_cast<u32x4*>(sK + key * ROWB + ((dc ^ (key & 7)) << 4)) = kreg[i];   // XOR-swizzled chunks
+      *reinterpret_cast<u32x4*>(sV + key * ROWB + (dc << 4)) = vreg[i];
+    }
+  };
+
+  issue_loads(0);
+  for (int t = 0; t < ntiles; ++t) {
+    __syncthreads();                 // every wave is done reading the previous tile
+    write_lds();
+    __syncthreads();
+    if (t + 1 < ntiles) issue_loads(t + 1);
+
+    const int kv0 = t * kKT;
+    if (kv0 > qw0 + kQW - 1) continue;   // tile entirely above this wave's diagonal (wave-uniform)
+
+    // ---- S^T = K . Q^T for the two 32-key halves of the tile
+    f32x16 st[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+      const int row = 32 * kt + c;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(sK + row * ROWB + (((2 * s + h) ^ (row & 7)) << 4));
+        st[kt] = Mma<Tag>::run(a, qf[s], st[kt]);
+      }
+    }
+    // ---- scale, causal mask, online softmax (the lane's query is column c)
+    const bool diag = kv0 + kKT - 1 > qw0;           // some key of the tile may exceed some query of the wave
+    float mx = -__builtin_inff();
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float s = st[kt][r] * p.scale_log2e;
+        if (diag) {
+          const int key = kv0 + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * h;
+          s = key <= my_q ? s : -__builtin_inff();
+        }
+        st[kt][r] = s;
+        mx = fmaxf(mx, s);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float f = fast_exp2(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = fast_exp2(st[kt][r] - m_new);
+        st[kt][r] = e;
+        psum += e;
+      }
+    psum += __shfl_xor(psum, 32);
+    l_run = l_run * f + psum;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] *= f;
+
+    // ---- O^T += V^T . P^T : k-step s4 covers keys 16*s4 .. 16*s4+15 of the tile.
+    // Fragment element j of lane half h is key 16*s4 + 8*(j>>2) + 4*h + (j&3): exactly
+    // registers 8*(s4&1) .. +7 of st[s4>>1] for P, and two transposing 4-key reads for V.
+    const int grp = (lane >> 4) & 1, qi = (lane & 15) >> 2, pi = lane & 3;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int kt = s4 >> 1, r0 = 8 * (s4 & 1);
+      u32x4 pb;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) pb[w] = Mma<Tag>::pack2(st[kt][r0 + 2 * w], st[kt][r0 + 2 * w + 1]);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        // lane 4*qi+pi of each 16-lane group addresses row (key) base+qi, columns d0+4*pi..+3;
+        // it receives column (lane&15) of the 4 rows = V[base+0..3][d0 + (lane&15)].
+        const int d0 = 32 * dt + 16 * grp;
+        const int key_lo = 16 * s4 + 4 * h + qi;
+        const unsigned char* a0 = sV + key_lo * ROWB + (d0 + 4 * pi) * 2;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(a0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(a0 + 8 * ROWB));
+        const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
+        const u32x4 va = {lo2[0], lo2[1], hi2[0], hi2[1]};
+        o[dt] = Mma<Tag>::run(va, pb, o[dt]);
+      }
+    }
+  }
+
+  // ---- normalise and store: lane (c,h) holds O[my_q][32*dt + 8*(r>>2) + 4*h + (r&3)]
+  if (my_q < len) {
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    char* dst = static_cast<char*>(p.out) + ((int64_t)(seq_start + my_q) * p.Hq + hq) * D * 2;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int d0 = 32 * dt + 8 * rg + 4 * h;
+        u32x2 w;
+        w[0] = Mma<Tag>::pack2(o[dt][4 * rg] * inv, o[dt][4 * rg + 1] * inv);
+        w[1] = Mma<Tag>::pack2(o[dt][4 * rg + 2] * inv, o[dt][4 * rg + 3] * inv);
+        *reinterpret_cast<u32x2*>(dst + d0 * 2) = w;
+      }
+  }
+}
+
+template <class Tag, int D>
+int launch(const PrefillParams& p, hipStream_t s) {
+  const int64_t grid = (int64_t)p.nseq * p.n_qt_max * p.Hq;
+  hipLaunchKernelGGL((prefill_mfma_kernel<Tag, D>), dim3((unsigned)grid), dim3(kWaves * kWave), 0, s, p);
+  return check_launch("prefill_mfma_kernel");
+}
+
+}  // namespace
+
+// Returns 1 when this kernel family covers (dtype, D); the caller then must not fall back.
+bool prefill_mfma_supported(int dtype, int D) {
+  return (dtype == MI355_BF16 || dtype == MI355_F16) && (D == 64 || D == 128);
+}
+
+int prefill_mfma_launch(void* out, const void* q, const void* k, const void* v, int64_t q_stride_tok,
+                        int64_t kv_stride_tok, const int32_t* cu_seqlens, int nseq, int total_tokens,
+                        int max_seqlen, int Hq, int Hkv, int D, float scale, int dtype, hipStream_t stream) {
+  PrefillParams p;
+  p.out = out;
+  p.q = q;
+  p.k = k;
+  p.v = v;
+  p.cu = cu_seqlens;
+  p.q_stride_tok = q_stride_tok;
+  p.kv_stride_tok = kv_stride_tok;
+  p.nseq = nseq;
+  p.n_qt_max = (max_seqlen + kQT - 1) / kQT;
+  p.Hq = Hq;
+  p.Hkv = Hkv;
+  p.total_tokens = total_tokens;
+  p.scale_log2e = scale * 1.4426950408889634f;
+  if (dtype == MI355_BF16) return D == 64 ? launch<BF16, 64>(p, stream) : launch<BF16, 128>(p, stream);
+  return D == 64 ? launch<F16, 64>(p, stream) : launch<F16, 128>(p, stream);
+}
+
+}  // namespace mi355
