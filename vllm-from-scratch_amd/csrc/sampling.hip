@@ -12,23 +12,54 @@ namespace {
 
 constexpr int kMaxWaves = 16;
 
-template <class T, class Op>
-__device__ __forceinline__ T wave_reduce(T v, Op op) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = op(v, __shfl_xor(v, off));
-  return v;
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ float lane_f(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 
-// All threads get the reduction over the workgroup.  scratch: kMaxWaves entries in LDS.
+// Wave-wide reductions, result in every lane.  Four DPP steps fold each row of 16 lanes
+// (xor 1, xor 2, half-row mirror, row mirror), four v_readlane combine the rows: no LDS,
+// no ds_bpermute.  All 64 lanes must be active.
+template <class Op>
+__device__ __forceinline__ float wave_reduce(float v, Op op) {
+  v = op(v, dpp_f<0xB1>(v));
+  v = op(v, dpp_f<0x4E>(v));
+  v = op(v, dpp_f<0x141>(v));
+  v = op(v, dpp_f<0x140>(v));
+  return op(op(lane_f(v, 0), lane_f(v, 16)), op(lane_f(v, 32), lane_f(v, 48)));
+}
+template <class Op>
+__device__ __forceinline__ int wave_reduce(int v, Op op) {
+  v = op(v, dpp_i<0xB1>(v));
+  v = op(v, dpp_i<0x4E>(v));
+  v = op(v, dpp_i<0x141>(v));
+  v = op(v, dpp_i<0x140>(v));
+  return op(op(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+            op(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+// Workgroup-wide reductions through a two-slot LDS exchange: call n uses slot n & 1, so one
+// barrier per call is enough (a wave can be at most one call ahead of the slowest reader).
+struct Exchange {
+  float f[2][kMaxWaves];
+  int c[2][kMaxWaves];
+};
+
 template <class T, class Op>
-__device__ __forceinline__ T block_reduce(T v, Op op, T* scratch) {
+__device__ __forceinline__ T block_reduce(T v, Op op, Exchange& x, int& slot) {
   v = wave_reduce(v, op);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  if (lane == 0) scratch[wave] = v;
+  T* buf;
+  if constexpr (sizeof(T) == 4 && __is_same(T, float)) buf = reinterpret_cast<T*>(x.f[slot]);
+  else buf = reinterpret_cast<T*>(x.c[slot]);
+  if (lane == 0) buf[wave] = v;
   __syncthreads();
-  T r = scratch[0];
-  for (int w = 1; w < nw; ++w) r = op(r, scratch[w]);
-  __syncthreads();
+  T r = buf[0];
+  for (int w = 1; w < nw; ++w) r = op(r, buf[w]);
+  slot ^= 1;
   return r;
 }
 
@@ -165,9 +196,10 @@ struct FC {  // (probability mass, count) pair reduced together
 // VPT == 0: they are recomputed from the logits on every pass (any vocab size).
 template <class Tag, int VPT, int NT>
 __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
-  __shared__ float s_f[kMaxWaves];
-  __shared__ int s_c[kMaxWaves];
+  __shared__ Exchange xch;
+  __shared__ float s_scan[kMaxWaves];
   __shared__ int s_pick;
+  int slot = 0;
   const int tid = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
   const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
   const typename Tag::elem_t* row = static_cast<const typename Tag::elem_t*>(p.logits) + (int64_t)b * p.row_stride;
@@ -181,24 +213,34 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
   auto addi = [](int a, int c) { return a + c; };
   auto maxi = [](int a, int c) { return max(a, c); };
 
-  // temperature-scaled logits: y = x / T, as the reference divides before softmax
-  float mx = -__builtin_inff();
-  for (int i = tid; i < vocab; i += nt) mx = fmaxf(mx, Tag::to_float(row[i]) / temp);
-  mx = block_reduce(mx, fmaxop, s_f);
-  float z = 0.f;
-  for (int i = tid; i < vocab; i += nt) z += expf(Tag::to_float(row[i]) / temp - mx);
-  z = block_reduce(z, addf, s_f);
-
-  auto prob_at = [&](int i) { return expf(Tag::to_float(row[i]) / temp - mx) / z; };
+  // p = softmax(x / T): the division comes first, as in the reference.  Register-resident
+  // rows are divided and exponentiated exactly once.
   constexpr int NR = VPT > 0 ? VPT : 1;
   float pr[NR];
+  float mx = -__builtin_inff(), z = 0.f;
   if constexpr (VPT > 0) {
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
       const int i = j * nt + tid;
-      pr[j] = i < vocab ? prob_at(i) : -1.0f;  // -1 marks "no element"
+      pr[j] = i < vocab ? Tag::to_float(row[i]) / temp : -__builtin_inff();
+      mx = fmaxf(mx, pr[j]);
     }
+    mx = block_reduce(mx, fmaxop, xch, slot);
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+      pr[j] = expf(pr[j] - mx);          // absent elements: exp(-inf) = 0
+      z += pr[j];
+    }
+    z = block_reduce(z, addf, xch, slot);
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) pr[j] = (j * nt + tid < vocab) ? pr[j] / z : -1.0f;   // -1 marks "no element"
+  } else {
+    for (int i = tid; i < vocab; i += nt) mx = fmaxf(mx, Tag::to_float(row[i]) / temp);
+    mx = block_reduce(mx, fmaxop, xch, slot);
+    for (int i = tid; i < vocab; i += nt) z += expf(Tag::to_float(row[i]) / temp - mx);
+    z = block_reduce(z, addf, xch, slot);
   }
+  auto prob_at = [&](int i) { return expf(Tag::to_float(row[i]) / temp - mx) / z; };
   // Visits every element this thread owns: fn(probability, index).
   auto for_each = [&](auto fn) {
     if constexpr (VPT > 0) {
@@ -212,25 +254,35 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
   // (mass, count) of elements strictly above v, over the whole row.
   auto above = [&](float v) {
     FC a = {0.f, 0};
-    for_each([&](float q, int) {
-      if (q > v) {
-        a.f += q;
-        a.c += 1;
+    if constexpr (VPT > 0) {
+      // v >= 0 and absent elements are -1, so no presence test is needed here
+#pragma unroll
+      for (int j = 0; j < VPT; ++j) {
+        const bool up = pr[j] > v;
+        a.f += up ? pr[j] : 0.f;
+        a.c += up ? 1 : 0;
       }
-    });
+    } else {
+      for_each([&](float q, int) {
+        if (q > v) {
+          a.f += q;
+          a.c += 1;
+        }
+      });
+    }
     a.f = wave_reduce(a.f, addf);
     a.c = wave_reduce(a.c, addi);
     if (lane == 0) {
-      s_f[wave] = a.f;
-      s_c[wave] = a.c;
+      xch.f[slot][wave] = a.f;
+      xch.c[slot][wave] = a.c;
     }
     __syncthreads();
-    FC r = {s_f[0], s_c[0]};
+    FC r = {xch.f[slot][0], xch.c[slot][0]};
     for (int w = 1; w < nw; ++w) {
-      r.f += s_f[w];
-      r.c += s_c[w];
+      r.f += xch.f[slot][w];
+      r.c += xch.c[slot][w];
     }
-    __syncthreads();
+    slot ^= 1;
     return r;
   };
 
@@ -242,7 +294,7 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
   if (!filter) {
     float s = 0.f;
     for_each([&](float q, int) { s += q; });
-    kept_mass = block_reduce(s, addf, s_f);
+    kept_mass = block_reduce(s, addf, xch, slot);
   } else {
     const int kk = tk > 0 ? tk : 0x7fffffff;
     // A value v survives (its first copy in descending order is kept) iff the mass
@@ -250,7 +302,7 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
     // predicate is monotone in v, so bisect on the bit pattern of a non-negative float.
     float pmax = 0.f;
     for_each([&](float q, int) { pmax = fmaxf(pmax, q); });
-    pmax = block_reduce(pmax, fmaxop, s_f);
+    pmax = block_reduce(pmax, fmaxop, xch, slot);
     uint32_t lo = 0u, hi = __builtin_bit_cast(uint32_t, pmax);
     while (lo < hi) {
       const uint32_t mid = lo + ((hi - lo) >> 1);
@@ -262,11 +314,11 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
     for_each([&](float q, int) {
       if (q >= u) vmin = fminf(vmin, q);
     });
-    vstar = block_reduce(vmin, fminop, s_f);
+    vstar = block_reduce(vmin, fminop, xch, slot);
     const FC a = above(vstar);
     int ties = 0;
     for_each([&](float q, int) { ties += (q == vstar); });
-    ties = block_reduce(ties, addi, s_c);
+    ties = block_reduce(ties, addi, xch, slot);
     // Number of tied copies kept: copy j (0-based) needs mass_above + j*v < top_p and count_above + j < k.
     int keep = ties;
     if (tp < 1.0f && vstar > 0.f) {
@@ -284,7 +336,7 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
         const int xm = xl + ((xh - xl) >> 1);
         int c = 0;
         for_each([&](float q, int i) { c += (q == vstar && i < xm); });
-        c = block_reduce(c, addi, s_c);
+        c = block_reduce(c, addi, xch, slot);
         if (c >= keep) xh = xm; else xl = xm + 1;
       }
       tie_end = xl;
@@ -316,16 +368,16 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
     const float o = __shfl_up(incl, off);
     if (lane >= off) incl += o;
   }
-  if (lane == 63) s_f[wave] = incl;
+  if (lane == 63) s_scan[wave] = incl;
   if (tid == 0) s_pick = 0x7fffffff;
   __syncthreads();
   float base = 0.f;
-  for (int w = 0; w < wave; ++w) base += s_f[w];
+  for (int w = 0; w < wave; ++w) base += s_scan[w];
   const float excl = base + incl - mine;
   if (mine > 0.f && excl <= target && target < excl + mine) atomicMin(&s_pick, tid);
   __syncthreads();
   const int picker = s_pick;
-  last_kept = block_reduce(last_kept, maxi, s_c);
+  last_kept = block_reduce(last_kept, maxi, xch, slot);
   if (picker == 0x7fffffff) {
     if (tid == 0) p.out[b] = max(last_kept, 0);  // rounding pushed the target past the total
     return;
