@@ -100,6 +100,48 @@ def test_decode_batched_ragged(ops, device, shape, dtype):
     np.testing.assert_allclose(out, want, **(F32_TOL if dtype == torch.float32 else LOWP_TOL))
 
 
+@pytest.mark.parametrize('shape', [
+    # B, Hq, Hkv, D, BS, max_ctx   -- block sizes from 1 to 128, many kv heads, wide query groups
+    (3, 8, 8, 64, 1, 40), (3, 8, 8, 64, 2, 77), (2, 8, 8, 64, 32, 200), (2, 4, 4, 128, 64, 300),
+    (2, 8, 8, 32, 128, 513), (2, 16, 16, 64, 16, 150), (2, 32, 32, 32, 16, 90), (2, 32, 2, 64, 16, 120),
+    (2, 24, 24, 16, 16, 65), (300, 8, 8, 64, 16, 48),
+])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+def test_decode_shape_sweep(ops, device, shape, dtype):
+    B, Hq, Hkv, D, BS, max_ctx = shape
+    rng = np.random.default_rng(hash(shape) % (2 ** 31))
+    q, cache, bt, ctx = _random_batch(rng, B, Hq, Hkv, D, BS, max_ctx)
+    ctx[0] = max_ctx                                   # one row ends exactly on max_context
+    if B > 1:
+        ctx[1] = max(1, (max_ctx // BS) * BS)          # one ends exactly on a block boundary
+    if dtype != torch.float32:
+        q = torch.from_numpy(q).to(dtype).float().numpy()
+        cache = torch.from_numpy(cache).to(dtype).float().numpy()
+    want = orc.paged_decode_batch(q, cache[0], cache[1], bt, ctx, BS, dtype=np.float64)
+    out = _decode_on_gpu(ops, device, q, cache, bt, ctx, dtype)
+    np.testing.assert_allclose(out, want, **(F32_TOL if dtype == torch.float32 else LOWP_TOL))
+
+
+def test_decode_ignores_unused_and_clamps_bad_block_ids(ops, device):
+    """Entries of a block-table row past ceil(context/block_size) are never read, whatever they
+    hold; ids outside the pool inside the used range are clamped (wrong answer for that row,
+    but no out-of-bounds access and no effect on other rows)."""
+    rng = np.random.default_rng(77)
+    q, cache, bt, ctx = _random_batch(rng, 4, 8, 8, 64, 16, 160, ragged=False)
+    ctx = [160, 33, 16, 97]
+    want = orc.paged_decode_batch(q, cache[0], cache[1], bt, ctx, 16, dtype=np.float64)
+    poisoned = bt.copy()
+    for b, n in enumerate(ctx):
+        poisoned[b, (n + 15) // 16:] = [-7, 2 ** 31 - 1, -2 ** 31, 123456789][b]
+    out = _decode_on_gpu(ops, device, q, cache, poisoned, ctx, torch.float32)
+    np.testing.assert_allclose(out, want, **F32_TOL)
+    bad = bt.copy()
+    bad[2, 0] = 2 ** 30                                 # inside the used range of row 2 only
+    out = _decode_on_gpu(ops, device, q, cache, bad, ctx, torch.float32)
+    np.testing.assert_allclose(out[[0, 1, 3]], want[[0, 1, 3]], **F32_TOL)
+    assert np.isfinite(out[2]).all()
+
+
 def test_decode_zero_context_rows(ops, device):
     rng = np.random.default_rng(5)
     q, cache, bt, ctx = _random_batch(rng, 4, 8, 8, 64, 16, 64)
