@@ -262,6 +262,71 @@ class Scheduler:
 # per-step attention plan (host) and the kernel-backed attention step
 # ---------------------------------------------------------------------------
 
+class DeviceBlockTables:
+    """Device-resident copy of the running requests' block tables: int32 [rows, width].
+
+    A request keeps one row while it runs.  Block tables only ever grow at the end, so each
+    step uploads just the entries appended since the last one (one small scatter) instead of
+    re-sending every table; a pure-decode step of B sequences moves about B / block_size ints.
+    Rows and width grow by doubling when the pool is exhausted.
+    """
+
+    def __init__(self, device, rows: int = 8, width: int = 8):
+        self.device = device
+        self.tables = torch.zeros((rows, width), dtype=torch.int32, device=device)
+        self._row_of: dict = {}
+        self._uploaded: dict = {}
+        self._free_rows = list(range(rows - 1, -1, -1))
+
+    def _grow(self, rows: int, width: int):
+        old = self.tables
+        new = torch.zeros((rows, width), dtype=torch.int32, device=self.device)
+        new[:old.shape[0], :old.shape[1]] = old
+        self._free_rows = list(range(rows - 1, old.shape[0] - 1, -1)) + self._free_rows
+        self.tables = new
+
+    def sync(self, requests: Sequence["Request"]) -> List[int]:
+        """Make sure every request has a row holding its current block table; returns the rows."""
+        need_width = max((len(r.block_table) for r in requests), default=0)
+        missing = sum(1 for r in requests if r.request_id not in self._row_of)
+        rows, width = self.tables.shape
+        if missing > len(self._free_rows) or need_width > width:
+            while missing > len(self._free_rows) + (rows - self.tables.shape[0]):
+                rows *= 2
+            while need_width > width:
+                width *= 2
+            self._grow(rows, width)
+        out, r_idx, c_idx, vals = [], [], [], []
+        for req in requests:
+            row = self._row_of.get(req.request_id)
+            if row is None:
+                row = self._free_rows.pop()
+                self._row_of[req.request_id] = row
+                self._uploaded[req.request_id] = 0
+            done = self._uploaded[req.request_id]
+            table = req.block_table
+            if len(table) > done:
+                r_idx.extend([row] * (len(table) - done))
+                c_idx.extend(range(done, len(table)))
+                vals.extend(table[done:])
+                self._uploaded[req.request_id] = len(table)
+            out.append(row)
+        if vals:
+            packed = torch.tensor([r_idx, c_idx, vals], dtype=torch.int64, device=self.device)
+            self.tables[packed[0], packed[1]] = packed[2].to(torch.int32)
+        return out
+
+    def release(self, request_id: str):
+        row = self._row_of.pop(request_id, None)
+        if row is not None:
+            self._uploaded.pop(request_id, None)
+            self._free_rows.append(row)
+
+    def gather(self, rows: Sequence[int]) -> torch.Tensor:
+        """[len(rows), width] int32 block tables for the given rows (device gather)."""
+        return self.tables.index_select(0, torch.tensor(rows, dtype=torch.int64, device=self.device))
+
+
 @dataclass
 class AttnPlan:
     """Which kernel serves which token of a flattened step.
@@ -285,14 +350,21 @@ class AttnPlan:
 
 def build_attn_plan(positions: Sequence[int], seq_lens: Sequence[int], is_prefill: Sequence[bool],
                     block_tables: Optional[Sequence[Sequence[int]]], device,
-                    reference_compat: bool = False) -> AttnPlan:
+                    reference_compat: bool = False,
+                    device_tables: Optional[DeviceBlockTables] = None,
+                    table_rows: Optional[Sequence[int]] = None) -> AttnPlan:
+    """block_tables: per-request lists of block ids (host), or None for the reference's
+    semantics.  When device_tables / table_rows are given (one row id per request) the paged
+    rows' tables are gathered on the device instead of being rebuilt from the host lists."""
     causal_tok: List[int] = []
     cu = [0]
     max_len = 0
     paged_tok: List[int] = []
     paged_ctx: List[int] = []
     paged_tab: List[Sequence[int]] = []
-    compat = reference_compat or block_tables is None
+    paged_row: List[int] = []
+    use_rows = device_tables is not None and table_rows is not None and not reference_compat
+    compat = reference_compat or (block_tables is None and not use_rows)
     tok = 0
     for r, (n, prefill) in enumerate(zip(seq_lens, is_prefill)):
         n_q = n if prefill else 1
@@ -306,6 +378,11 @@ def build_attn_plan(positions: Sequence[int], seq_lens: Sequence[int], is_prefil
             paged_tok.append(tok)
             paged_ctx.append(1)
             paged_tab.append((0,))
+        elif use_rows:
+            for j in range(n_q):
+                paged_tok.append(tok + j)
+                paged_ctx.append(positions[tok + j] + 1)
+                paged_row.append(table_rows[r])
         else:
             table = block_tables[r]
             for j in range(n_q):
@@ -328,9 +405,12 @@ def build_attn_plan(positions: Sequence[int], seq_lens: Sequence[int], is_prefil
         plan.cu_seqlens = torch.tensor(cu, dtype=torch.int32, device=device)
     if paged_tok:
         plan.paged_index = idx(paged_tok)
-        width = max(len(t) for t in paged_tab)
-        rows = [list(t) + [0] * (width - len(t)) for t in paged_tab]
-        plan.paged_tables = torch.tensor(rows, dtype=torch.int32, device=device)
+        if paged_row:
+            plan.paged_tables = device_tables.gather(paged_row)
+        else:
+            width = max(len(t) for t in paged_tab)
+            rows = [list(t) + [0] * (width - len(t)) for t in paged_tab]
+            plan.paged_tables = torch.tensor(rows, dtype=torch.int32, device=device)
         plan.paged_context = torch.tensor(paged_ctx, dtype=torch.int32, device=device)
     return plan
 
@@ -498,18 +578,21 @@ class MiniTransformer(nn.Module):
                 seq_lens: List[int], is_prefill: List[bool],
                 block_tables: Optional[Sequence[Sequence[int]]] = None,
                 positions_host: Optional[Sequence[int]] = None,
-                reference_compat: bool = False) -> torch.Tensor:
+                reference_compat: bool = False,
+                device_tables: Optional[DeviceBlockTables] = None,
+                table_rows: Optional[Sequence[int]] = None) -> torch.Tensor:
         """Logits [batch, vocab] for the last token of every request in the flattened step.
 
         The five leading arguments are the reference's; block_tables (one list of physical
         block ids per request) enables attention over the true paged context, positions_host
-        is an optional host copy of `positions` that saves a device read-back."""
+        is an optional host copy of `positions` that saves a device read-back; device_tables +
+        table_rows (what MiniVLLM passes) replace block_tables by rows of a persistent device copy."""
         home = self.embedding.weight.device
         token_ids, positions, slot_mapping = (t.to(home) for t in (token_ids, positions, slot_mapping))
         if positions_host is None:
             positions_host = positions.tolist()
         plan = build_attn_plan(positions_host, seq_lens, is_prefill, block_tables,
-                               _compute_device(self.k_cache), reference_compat)
+                               _compute_device(self.k_cache), reference_compat, device_tables, table_rows)
         x = self.embedding(token_ids)
         for i, layer in enumerate(self.layers):
             x = layer(x, positions, (self.k_cache[i], self.v_cache[i]), slot_mapping, seq_lens, is_prefill, plan)
@@ -594,6 +677,7 @@ class MiniVLLM:
             self.model = self.model.to(dtype)
         self.sampler = Sampler()
         self._req_counter = 0
+        self._device_tables: Optional[DeviceBlockTables] = None   # created on first use (needs a HIP device)
 
     def add_request(self, prompt_token_ids: List[int], max_new_tokens: int = 20,
                     temperature: float = 1.0, top_p: float = 1.0) -> str:
@@ -621,14 +705,24 @@ class MiniVLLM:
         prefill_flags = [item.is_prefill for item in scheduled]
         requests = [item.request for item in scheduled]
 
+        rows = None
+        if not self.reference_compat:
+            if self._device_tables is None:
+                self._device_tables = DeviceBlockTables(_compute_device(self.model.k_cache),
+                                                        rows=max(8, self.scheduler.max_num_seqs))
+            rows = self._device_tables.sync(requests)
         as_long = dict(dtype=torch.long, device=self.device)
         with torch.no_grad():
             logits = self.model(torch.tensor(tokens, **as_long), torch.tensor(positions, **as_long),
                                 torch.tensor(slots, **as_long), seq_lens, prefill_flags,
-                                block_tables=[r.block_table for r in requests],
-                                positions_host=positions, reference_compat=self.reference_compat)
+                                positions_host=positions, reference_compat=self.reference_compat,
+                                device_tables=self._device_tables, table_rows=rows)
         next_tokens = self.sampler.sample(logits, requests)
         self.scheduler.update(scheduled, next_tokens)
+        if self._device_tables is not None:
+            for req in requests:
+                if req.is_finished:
+                    self._device_tables.release(req.request_id)
         return [(item.request.request_id, tok) for item, tok in zip(scheduled, next_tokens)
                 if not (item.is_prefill and item.request.is_prefill)]
 
