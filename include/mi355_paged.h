@@ -163,6 +163,37 @@ int mi355_slot_mapping(int64_t* out_slots, const int32_t* block_tables, const in
                        const int32_t* cu_tokens, int32_t B, int32_t max_blocks,
                        int32_t block_size, int32_t total_tokens, void* stream);
 
+/*
+ * Latent-space MLA attention (weight-absorbed form) for `rows` query rows.  Replaces steps
+ * 3-7 of MultiHeadLatentAttention.forward (04_mla/mini_mla.py:234-299): instead of expanding
+ * every cached c_kv row to per-head K and V, heads attend directly to the cached rows
+ *
+ *   score[h][t] = scale * ( q[h][:R] . c_kv[t]  +  q[h][R:] . rope(k_rope[t], position t) )
+ *   out[h]      = softmax_t(score[h]) . c_kv[t]                    -> [rows, H, R] fp32
+ *
+ * where the caller has folded the key up-projection into q[:, :, :R] and applies the value
+ * up-projection to `out`.  rope() is the rotate-half form with cos/sin tables [table_len, P]
+ * (fp32; cos[t][i] == cos[t][i + P/2]); cached k_rope is stored un-rotated, as the reference
+ * caches it, and token t of a sequence sits at position t.
+ *   q         [rows, H, R+P] (q_stride_row elements between rows), bf16 / f16
+ *   c_kv      row of token t of sequence s at  s*ckv_stride_seq + t*ckv_stride_tok   (R elements)
+ *   k_rope    likewise with the krope strides                                           (P elements)
+ *   context_lens [rows]; row_seq [rows] = cache sequence each row reads (NULL: row i reads i) --
+ *             lets T query tokens of one sequence be T rows with context past + t + 1 (causal)
+ *   R in {32,64,128,256,512}; P a multiple of 8, <= 64
+ */
+int mi355_mla_decode(float* out, const void* q, int64_t q_stride_row,
+                     const void* c_kv, int64_t ckv_stride_seq, int64_t ckv_stride_tok,
+                     const void* k_rope, int64_t krope_stride_seq, int64_t krope_stride_tok,
+                     const float* cos_table, const float* sin_table, int32_t table_len,
+                     const int32_t* context_lens, const int32_t* row_seq,
+                     int32_t rows, int32_t H, int32_t R, int32_t P, int32_t max_context,
+                     float scale, int32_t dtype, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Scratch bytes mi355_mla_decode needs for this shape. */
+size_t mi355_mla_decode_workspace_bytes(int32_t rows, int32_t H, int32_t R, int32_t P,
+                                        int32_t max_context, int32_t dtype);
+
 #ifdef __cplusplus
 }
 #endif

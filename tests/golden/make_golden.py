@@ -334,7 +334,64 @@ def g8():
     save_npz('g8_engine_greedy.npz', **arrays)
 
 
+
+
+# ---------------------------------------------------------------- G9 (MLA, 04_mla/mini_mla.py)
+def g9():
+    sys.path.insert(0, os.path.join(REF, '04_mla'))
+    import mini_mla as ref_mla
+    arrays, meta = {}, []
+    cfgs = [dict(hidden_size=128, num_heads=4, qk_nope_head_dim=16, qk_rope_head_dim=8, kv_lora_rank=32,
+                 v_head_dim=16, max_seq_len=256),          # the reference test-suite's small_mla
+            dict(hidden_size=128, num_heads=8, qk_nope_head_dim=32, qk_rope_head_dim=16, kv_lora_rank=64,
+                 v_head_dim=32, max_seq_len=256)]
+    for ci, cfg in enumerate(cfgs):
+        torch.manual_seed(100 + ci)
+        m = ref_mla.MultiHeadLatentAttention(**cfg).eval()
+        with torch.no_grad():
+            for prm in m.parameters():                      # fp16-representable weights: half the fixture size
+                prm.copy_(prm.half().float())
+        for k, v in m.state_dict().items():
+            if 'rotary' not in k:
+                arrays[f'm{ci}_w::{k}'] = v.numpy().astype(np.float16)
+        g = torch.Generator().manual_seed(7 + ci)
+        B, T0 = 2, 12 + ci * 9
+        calls = []
+        with torch.no_grad():
+            x = torch.randn(B, T0, cfg['hidden_size'], generator=g)
+            pos = torch.arange(T0).unsqueeze(0).expand(B, -1)
+            out, c_kv, k_rope = m(x, pos)
+            calls.append(('prefill', x, pos, None, None, out, c_kv, k_rope))
+            for step in range(3):
+                xd = torch.randn(B, 1, cfg['hidden_size'], generator=g)
+                pd = torch.full((B, 1), c_kv.shape[1])
+                out, nc, nr = m(xd, pd, past_c_kv=c_kv, past_k_rope=k_rope)
+                calls.append((f'decode{step}', xd, pd, c_kv, k_rope, out, nc, nr))
+                c_kv, k_rope = torch.cat([c_kv, nc], 1), torch.cat([k_rope, nr], 1)
+            xc = torch.randn(B, 5, cfg['hidden_size'], generator=g)
+            pc = torch.arange(c_kv.shape[1], c_kv.shape[1] + 5).unsqueeze(0).expand(B, -1)
+            out, nc, nr = m(xc, pc, past_c_kv=c_kv, past_k_rope=k_rope)
+            calls.append(('chunk', xc, pc, c_kv, k_rope, out, nc, nr))
+        names = []
+        for name, x, pos, pc_, pr_, out, nc, nr in calls:
+            names.append(name)
+            pre = f'm{ci}_{name}_'
+            arrays[pre + 'x'] = x.numpy()
+            arrays[pre + 'pos'] = pos.numpy()
+            if pc_ is not None:
+                arrays[pre + 'past_c_kv'] = pc_.numpy()
+                arrays[pre + 'past_k_rope'] = pr_.numpy()
+            arrays[pre + 'out'] = out.numpy()
+            arrays[pre + 'new_c_kv'] = nc.numpy()
+            arrays[pre + 'new_k_rope'] = nr.numpy()
+        meta.append(dict(config=cfg, calls=names))
+    mha, mla = ref_mla.compare_kv_cache_size(num_heads=32, head_dim=128, kv_lora_rank=512, qk_rope_head_dim=64,
+                                             num_layers=32, seq_len=4096, batch_size=1)
+    arrays['meta'] = np.array(json.dumps(dict(models=meta, kv_size_mb=[mha, mla])))
+    save_npz('g9_mla.npz', **arrays)
+
+
 if __name__ == '__main__':
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9):
         fn()
         print('wrote', fn.__name__)

@@ -109,3 +109,55 @@ def test_c_port_known_answer_and_batch():
     ctx = [12, 0, 5]
     want = orc.paged_decode_batch(q, kc[0], kc[1], bt, ctx, 4)
     np.testing.assert_allclose(c_port.paged_decode(q, kc[0], kc[1], bt, ctx), want, atol=1e-5, rtol=1e-5)
+
+
+# ------------------------------------------------------------------ MLA (04_mla)
+def _mla_models():
+    import json
+    z = load_npz('g9_mla.npz')
+    meta = json.loads(str(z['meta']))
+    for ci, m in enumerate(meta['models']):
+        w = {k[len(f'm{ci}_w::'):]: z[k].astype(np.float32) for k in z.files if k.startswith(f'm{ci}_w::')}
+        yield ci, m['config'], m['calls'], w, z
+
+
+def test_g9_mla_forward_matches_reference():
+    from oracle import mla_oracle as mo
+    for ci, cfg, calls, w, z in _mla_models():
+        for name in calls:
+            pre = f'm{ci}_{name}_'
+            past = (z[pre + 'past_c_kv'], z[pre + 'past_k_rope']) if pre + 'past_c_kv' in z.files else (None, None)
+            out, nc, nr = mo.mla_forward(w, cfg, z[pre + 'x'], z[pre + 'pos'], *past)
+            np.testing.assert_allclose(out, z[pre + 'out'], atol=2e-5, rtol=1e-4)
+            np.testing.assert_allclose(nc, z[pre + 'new_c_kv'], atol=1e-5, rtol=1e-5)
+            np.testing.assert_allclose(nr, z[pre + 'new_k_rope'], atol=1e-5, rtol=1e-5)
+
+
+def test_g9_absorbed_form_equals_expanded_form():
+    """The latent-space formulation the kernel implements reproduces the reference outputs."""
+    from oracle import mla_oracle as mo
+    for ci, cfg, calls, w, z in _mla_models():
+        H, nope, rope, lora, vd = (cfg[k] for k in ('num_heads', 'qk_nope_head_dim', 'qk_rope_head_dim',
+                                                    'kv_lora_rank', 'v_head_dim'))
+        for name in calls:
+            pre = f'm{ci}_{name}_'
+            x, pos = z[pre + 'x'].astype(np.float64), z[pre + 'pos']
+            W = {k: v.astype(np.float64) for k, v in w.items()}
+            B, T, _ = x.shape
+            q = mo.rms_norm(x @ W['q_a_proj.weight'].T, W['q_a_layernorm.weight'], eps=np.finfo(np.float32).eps)
+            q = (q @ W['q_b_proj.weight'].T).reshape(B, T, H, nope + rope)
+            c_kv, k_rope = z[pre + 'new_c_kv'].astype(np.float64), z[pre + 'new_k_rope'].astype(np.float64)
+            if pre + 'past_c_kv' in z.files:
+                c_kv = np.concatenate([z[pre + 'past_c_kv'], c_kv], 1)
+                k_rope = np.concatenate([z[pre + 'past_k_rope'], k_rope], 1)
+            S = c_kv.shape[1]
+            cos, sin = mo.rope_tables(rope, S + 8, dtype=np.float64)
+            q_rope = q[..., nope:] * cos[pos][:, :, None] + mo.rotate_half(q[..., nope:]) * sin[pos][:, :, None]
+            q_cat = np.concatenate([mo.absorb_query(q[..., :nope], W['kv_b_proj.weight'], H, nope, vd), q_rope], -1)
+            rows = q_cat.reshape(B * T, H, lora + rope)
+            ctx = (pos + 1).reshape(-1)
+            row_seq = np.repeat(np.arange(B), T)
+            o_lat = mo.latent_attention(rows, c_kv, k_rope, cos, sin, ctx, (nope + rope) ** -0.5, row_seq)
+            o = mo.expand_output(o_lat, W['kv_b_proj.weight'], H, nope, vd).reshape(B, T, H * vd)
+            out = o @ W['o_proj.weight'].T
+            np.testing.assert_allclose(out, z[pre + 'out'], atol=2e-5, rtol=1e-4)

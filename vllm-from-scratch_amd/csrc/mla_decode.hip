@@ -1,0 +1,372 @@
+// Latent-space (weight-absorbed) MLA attention on the matrix cores.
+//
+// Multi-head Latent Attention caches, per token, one low-rank vector c_kv [R] shared by
+// all heads plus a small un-rotated RoPE key k_rope [P].  With the up-projections
+// absorbed into the query and the output (done by the caller with dense GEMMs), the
+// attention core is multi-query attention over rows [c_kv | rope(k_rope, pos)]:
+//
+//   score[h][t] = scale * ( q_lat[h] . c_kv[t]  +  q_rope[h] . rope(k_rope[t], t) )
+//   o_lat[h]    = softmax_t(score[h]) . c_kv[t]                     (value = the same c_kv)
+//
+// Every cached row is read ONCE for all heads, and H heads x (R + P) dims of work per row
+// is a real dense contraction, so this runs on v_mfma_f32_16x16x32:
+//
+//   workgroup = one wave = (query row, token split, tile of 16 heads); per step 16 tokens:
+//   rows are staged in LDS (k_rope rotated in place with the cos/sin of the token's
+//   position), S^T[token][head] = K . Q^T takes (R+P)/32 MFMAs with the 16 token rows as
+//   A and the query fragments (registers) as B; the softmax statistics of a head are
+//   lane-local plus two cross-lane steps; P^T goes straight from the accumulator registers
+//   into the B operand of O^T[d][head] += V^T . P^T, whose A operand (4 tokens x 16 dims
+//   per 16-lane group) is read from the same LDS rows with the transposing
+//   ds_read_b64_tr_b16.  Memory latency is hidden by occupancy (8 one-wave workgroups per
+//   CU, ~18 KiB of loads each), not by software pipelining.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace mi355 {
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kTok = 16;        // tokens per step
+constexpr int kHeadTile = 16;   // heads per workgroup
+
+struct MlaParams {
+  float* out;            // [rows, H, R] fp32
+  const void* q;         // [rows, H, R + P]
+  const void* ckv;       // c_kv rows
+  const void* krope;     // k_rope rows (un-rotated)
+  const float* cos_t;    // [table_len, P]
+  const float* sin_t;
+  const int32_t* ctx;    // [rows]
+  const int32_t* row_seq;  // [rows] cache sequence of each query row, or null (= row)
+  float* ws_acc;         // [rows, H, nsplit, R]
+  float* ws_ml;          // [rows, H, nsplit, 2]
+  int64_t q_stride_row, ckv_stride_seq, ckv_stride_tok, krope_stride_seq, krope_stride_tok;
+  int rows, H, P, table_len, max_ctx, n_ht, nsplit, tps;
+  float scale_log2e;
+};
+
+template <class Tag>
+struct Mma16;
+template <>
+struct Mma16<BF16> {
+  static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b),
+                                                   c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    return BF16::round1(lo) | (BF16::round1(hi) << 16);
+  }
+  static __device__ __forceinline__ uint16_t from_f(float x) { return (uint16_t)BF16::round1(x); }
+};
+template <>
+struct Mma16<F16> {
+  static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c,
+                                                  0, 0, 0);
+  }
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    f16x2_t h;
+    h[0] = (_Float16)lo;
+    h[1] = (_Float16)hi;
+    return __builtin_bit_cast(uint32_t, h);
+  }
+  static __device__ __forceinline__ uint16_t from_f(float x) {
+    return __builtin_bit_cast(uint16_t, (_Float16)x);
+  }
+};
+
+template <class Tag, int R, int PP>
+__global__ void __launch_bounds__(kWave) mla_decode_kernel(const MlaParams p) {
+  constexpr int DK = R + PP;              // key dims incl. zero padding of the rope part
+  constexpr int KS = DK / 32;             // MFMA k-steps of the score product
+  constexpr int OT = R / 16;              // 16-dim tiles of the latent output
+  constexpr int CPR = DK / 8;             // 16-byte chunks per staged row
+  constexpr int ROWB = DK * 2 + 16;       // LDS row pitch (16 B of padding staggers the banks)
+  constexpr int NCH = kTok * CPR;         // chunks per step
+  __shared__ __attribute__((aligned(16))) unsigned char tile[kTok * ROWB];
+
+  const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+  int bid = blockIdx.x;
+  const int ht = bid % p.n_ht;
+  bid /= p.n_ht;
+  const int sp = bid % p.nsplit;
+  const int row = bid / p.nsplit;
+  const int seq = p.row_seq ? p.row_seq[row] : row;
+  const int ctx = max(0, min(p.ctx[row], p.max_ctx));
+  const int t_begin = sp * p.tps;
+  if (p.nsplit > 1 && t_begin >= ctx) return;
+  const int t_end = min(ctx, t_begin + p.tps);
+  const int head = ht * kHeadTile + c;          // this lane's query head (column of S^T / O^T)
+  const bool head_ok = head < p.H;
+
+  // Query fragments: B operand, lane (c,g) holds Q[head c][32*ks + 8*g .. +8); zero beyond R+P and for padded heads.
+  u32x4 qf[KS];
+  {
+    const char* qrow = static_cast<const char*>(p.q) + ((int64_t)row * p.q_stride_row + (int64_t)head * (R + p.P)) * 2;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int d = 32 * ks + 8 * g;
+      const bool ok = head_ok && (d < R || d - R < p.P);
+      qf[ks] = ok ? *reinterpret_cast<const u32x4*>(qrow + d * 2) : u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+
+  f32x4 o[OT];
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot) o[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -1.0e30f, l_run = 0.f;
+
+  const char* ckv = static_cast<const char*>(p.ckv) + (int64_t)seq * p.ckv_stride_seq * 2;
+  const char* krope = static_cast<const char*>(p.krope) + (int64_t)seq * p.krope_stride_seq * 2;
+  const int half = p.P >> 1;
+
+  for (int t0 = t_begin; t0 < t_end; t0 += kTok) {
+    // ---- stage 16 rows [c_kv | k_rope | 0-pad] in LDS
+#pragma unroll 6
+    for (int ch = lane; ch < NCH; ch += kWave) {
+      const int tt = ch / CPR, dc = ch - tt * CPR;
+      const int tok = min(t0 + tt, t_end - 1);        // rows past the end re-read the last one (masked below)
+      const int d = dc * 8;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (d < R) v = load16<true>(ckv + ((int64_t)tok * p.ckv_stride_tok + d) * 2);
+      else if (d - R < p.P) v = load16<true>(krope + ((int64_t)tok * p.krope_stride_tok + (d - R)) * 2);
+      *reinterpret_cast<u32x4*>(tile + tt * ROWB + dc * 16) = v;
+    }
+    __syncthreads();
+    // ---- rotate the rope part in place: token c, position = its index in the sequence
+    {
+      const int pos = min(min(t0 + c, t_end - 1), p.table_len - 1);
+      typename Tag::elem_t* kr = reinterpret_cast<typename Tag::elem_t*>(tile + c * ROWB + R * 2);
+      const float* cs = p.cos_t + (int64_t)pos * p.P;
+      const float* sn = p.sin_t + (int64_t)pos * p.P;
+      for (int i0 = 8 * g; i0 < half; i0 += 32) {
+        for (int e = 0; e < 8 && i0 + e < half; ++e) {
+          const int i = i0 + e;
+          const float lo = Tag::to_float(kr[i]), hi = Tag::to_float(kr[i + half]);
+          const float co = cs[i], si = sn[i];
+          kr[i] = Mma16<Tag>::from_f(lo * co - hi * si);
+          kr[i + half] = Mma16<Tag>::from_f(hi * co + lo * si);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- S^T[token][head] = K . Q^T : A = 16 token rows, lane (r=c, g) reads row c, dims 32*ks + 8*g .. +8
+    f32x4 st = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const u32x4 a = *reinterpret_cast<const u32x4*>(tile + c * ROWB + (32 * ks + 8 * g) * 2);
+      st = Mma16<Tag>::run(a, qf[ks], st);
+    }
+    // lane (c,g) now holds S^T[token 4g + j][head c], j = 0..3
+    float s[4], mx = -__builtin_inff();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s[j] = (t0 + 4 * g + j < t_end) ? st[j] * p.scale_log2e : -__builtin_inff();
+      mx = fmaxf(mx, s[j]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float f = fast_exp2(m_run - m_new);
+    m_run = m_new;
+    float ps = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s[j] = fast_exp2(s[j] - m_new);
+      ps += s[j];
+    }
+    ps += __shfl_xor(ps, 16);
+    ps += __shfl_xor(ps, 32);
+    l_run = l_run * f + ps;
+    if (!__all(f == 1.0f)) {
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) o[ot] *= f;
+    }
+    // ---- O^T[d][head] += V^T . P^T.  MFMA k-slot (g, j) carries token 4g + j for j < 4 and
+    // nothing for j >= 4 (both operands zero there), so P^T is the accumulator registers as
+    // they stand and V^T is one transposing 4-row read per 16-dim tile.
+    const u32x4 pb = {Mma16<Tag>::pack2(s[0], s[1]), Mma16<Tag>::pack2(s[2], s[3]), 0u, 0u};
+    const int qi = c >> 2, pi = c & 3;
+    const unsigned char* vrow = tile + (4 * g + qi) * ROWB + (4 * pi) * 2;
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+      const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) s16x4*)(vrow + ot * 32));
+      const u32x2 t2 = __builtin_bit_cast(u32x2, t);
+      const u32x4 va = {t2[0], t2[1], 0u, 0u};
+      o[ot] = Mma16<Tag>::run(va, pb, o[ot]);
+    }
+    __syncthreads();   // the rows are overwritten by the next step
+  }
+
+  if (!head_ok) return;
+  // lane (c,g) holds O[head c][16*ot + 4*g + j]
+  if (p.nsplit == 1) {
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    float* dst = p.out + ((int64_t)row * p.H + head) * R + 4 * g;
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) *reinterpret_cast<f32x4*>(dst + 16 * ot) = o[ot] * inv;
+  } else {
+    const int64_t rec = ((int64_t)row * p.H + head) * p.nsplit + sp;
+    float* dst = p.ws_acc + rec * R + 4 * g;
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) *reinterpret_cast<f32x4*>(dst + 16 * ot) = o[ot];
+    if (g == 0) {
+      p.ws_ml[rec * 2] = m_run;
+      p.ws_ml[rec * 2 + 1] = l_run;
+    }
+  }
+}
+
+template <int R>
+__global__ void __launch_bounds__(256) mla_merge_kernel(const MlaParams p) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)p.rows * p.H * (R / 4);
+  if (idx >= total) return;
+  const int dv = (int)(idx % (R / 4));
+  const int64_t rh = idx / (R / 4);
+  const int row = (int)(rh / p.H);
+  const int ctx = max(0, min(p.ctx[row], p.max_ctx));
+  const int nvalid = min(p.nsplit, (ctx + p.tps - 1) / p.tps);
+  const float* ml = p.ws_ml + rh * p.nsplit * 2;
+  const float* pa = p.ws_acc + rh * p.nsplit * R + dv * 4;
+  float M = -1.0e30f;
+  for (int s = 0; s < nvalid; ++s) M = fmaxf(M, ml[2 * s]);
+  float den = 0.f;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < nvalid; ++s) {
+    const float f = fast_exp2(ml[2 * s] - M);
+    den = __builtin_fmaf(ml[2 * s + 1], f, den);
+    acc += *reinterpret_cast<const f32x4*>(pa + (size_t)s * R) * f;
+  }
+  const float inv = den > 0.f ? 1.f / den : 0.f;
+  *reinterpret_cast<f32x4*>(p.out + rh * R + dv * 4) = acc * inv;
+}
+
+struct MlaPlan {
+  int n_ht, nsplit, tps;
+  size_t ws_bytes;
+};
+
+int env_int2(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return (s && *s) ? atoi(s) : dflt;
+}
+
+int mla_plan(int rows, int H, int R, int P, int max_context, int dtype, MlaPlan* out) {
+  if (rows <= 0 || H <= 0) return fail(MI355_EINVAL, "mla_decode: rows/H (%d,%d)", rows, H);
+  if (dtype != MI355_BF16 && dtype != MI355_F16)
+    return fail(MI355_EUNSUPPORTED, "mla_decode: dtype %d (bf16 / f16 only)", dtype);
+  if (R != 32 && R != 64 && R != 128 && R != 256 && R != 512)
+    return fail(MI355_EUNSUPPORTED, "mla_decode: kv_lora_rank %d not in {32,64,128,256,512}", R);
+  if (P <= 0 || P > 64 || P % 8) return fail(MI355_EUNSUPPORTED, "mla_decode: rope dim %d (multiple of 8, <= 64)", P);
+  if (max_context < 0) return fail(MI355_EINVAL, "mla_decode: max_context %d", max_context);
+  MlaPlan pl;
+  pl.n_ht = (H + kHeadTile - 1) / kHeadTile;
+  const int ctx = max_context > 0 ? max_context : 1;
+  const int64_t base = (int64_t)rows * pl.n_ht;
+  const int target = env_int2("MI355_MLA_TARGET_WGS", 2048);   // 8 one-wave workgroups per CU
+  int64_t want = ceil_div64(target, base);
+  const int64_t most = ctx / 64 > 0 ? ctx / 64 : 1;             // at least 4 steps per workgroup
+  if (want > most) want = most;
+  if (want < 1) want = 1;
+  pl.tps = (int)(ceil_div64(ceil_div64(ctx, want), kTok) * kTok);
+  pl.nsplit = (int)ceil_div64(ctx, pl.tps);
+  pl.ws_bytes = pl.nsplit > 1 ? (size_t)rows * H * pl.nsplit * (R + 2) * sizeof(float) : 0;
+  *out = pl;
+  return 0;
+}
+
+template <class Tag, int R>
+int launch_r(const MlaParams& p, hipStream_t s) {
+  const int64_t grid = (int64_t)p.rows * p.nsplit * p.n_ht;
+  if (p.P <= 32) hipLaunchKernelGGL((mla_decode_kernel<Tag, R, 32>), dim3((unsigned)grid), dim3(kWave), 0, s, p);
+  else hipLaunchKernelGGL((mla_decode_kernel<Tag, R, 64>), dim3((unsigned)grid), dim3(kWave), 0, s, p);
+  if (int rc = check_launch("mla_decode_kernel")) return rc;
+  if (p.nsplit > 1) {
+    const int64_t threads = (int64_t)p.rows * p.H * (R / 4);
+    hipLaunchKernelGGL((mla_merge_kernel<R>), dim3((unsigned)ceil_div64(threads, 256)), dim3(256), 0, s, p);
+    return check_launch("mla_merge_kernel");
+  }
+  return 0;
+}
+
+template <class Tag>
+int launch_t(int R, const MlaParams& p, hipStream_t s) {
+  switch (R) {
+    case 32: return launch_r<Tag, 32>(p, s);
+    case 64: return launch_r<Tag, 64>(p, s);
+    case 128: return launch_r<Tag, 128>(p, s);
+    case 256: return launch_r<Tag, 256>(p, s);
+    case 512: return launch_r<Tag, 512>(p, s);
+  }
+  return fail(MI355_EUNSUPPORTED, "mla_decode: kv_lora_rank %d", R);
+}
+
+}  // namespace
+}  // namespace mi355
+
+using namespace mi355;
+
+extern "C" size_t mi355_mla_decode_workspace_bytes(int32_t rows, int32_t H, int32_t R, int32_t P,
+                                                   int32_t max_context, int32_t dtype) {
+  MlaPlan pl;
+  if (mla_plan(rows, H, R, P, max_context, dtype, &pl)) return 0;
+  return pl.ws_bytes;
+}
+
+extern "C" int mi355_mla_decode(float* out, const void* q, int64_t q_stride_row, const void* c_kv,
+                                int64_t ckv_stride_seq, int64_t ckv_stride_tok, const void* k_rope,
+                                int64_t krope_stride_seq, int64_t krope_stride_tok, const float* cos_table,
+                                const float* sin_table, int32_t table_len, const int32_t* context_lens,
+                                const int32_t* row_seq, int32_t rows, int32_t H, int32_t R, int32_t P,
+                                int32_t max_context, float scale, int32_t dtype, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  if (rows == 0) return 0;
+  if (!out || !q || !c_kv || !k_rope || !cos_table || !sin_table || !context_lens)
+    return fail(MI355_EINVAL, "mla_decode: null pointer argument");
+  MlaPlan pl;
+  if (int rc = mla_plan(rows, H, R, P, max_context, dtype, &pl)) return rc;
+  if (table_len <= 0) return fail(MI355_EINVAL, "mla_decode: empty cos/sin table");
+  if (q_stride_row % 8 || ckv_stride_tok % 8 || ckv_stride_seq % 8 || krope_stride_tok % 8 || krope_stride_seq % 8 ||
+      q_stride_row < (int64_t)H * (R + P) || ckv_stride_tok < R || krope_stride_tok < P)
+    return fail(MI355_EINVAL, "mla_decode: strides must keep rows 16-byte aligned");
+  if (((uintptr_t)out | (uintptr_t)q | (uintptr_t)c_kv | (uintptr_t)k_rope) & 15)
+    return fail(MI355_EINVAL, "mla_decode: tensors must be 16-byte aligned");
+  if (pl.ws_bytes && (!workspace || workspace_bytes < pl.ws_bytes || ((uintptr_t)workspace & 15)))
+    return fail(MI355_EWORKSPACE, "mla_decode: need %zu workspace bytes (16-B aligned), got %zu", pl.ws_bytes,
+                workspace ? workspace_bytes : (size_t)0);
+  MlaParams p;
+  p.out = out;
+  p.q = q;
+  p.ckv = c_kv;
+  p.krope = k_rope;
+  p.cos_t = cos_table;
+  p.sin_t = sin_table;
+  p.ctx = context_lens;
+  p.row_seq = row_seq;
+  p.ws_acc = static_cast<float*>(workspace);
+  p.ws_ml = p.ws_acc ? p.ws_acc + (size_t)rows * H * pl.nsplit * R : nullptr;
+  p.q_stride_row = q_stride_row;
+  p.ckv_stride_seq = ckv_stride_seq;
+  p.ckv_stride_tok = ckv_stride_tok;
+  p.krope_stride_seq = krope_stride_seq;
+  p.krope_stride_tok = krope_stride_tok;
+  p.rows = rows;
+  p.H = H;
+  p.P = P;
+  p.table_len = table_len;
+  p.max_ctx = max_context;
+  p.n_ht = pl.n_ht;
+  p.nsplit = pl.nsplit;
+  p.tps = pl.tps;
+  p.scale_log2e = scale * 1.4426950408889634f;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == MI355_BF16 ? launch_t<BF16>(R, p, s) : launch_t<F16>(R, p, s);
+}

@@ -34,6 +34,11 @@ SIGNATURES = {
     'mi355_sample_topk_topp': (c_int, [
         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_uint64, c_int32, c_int32,
         c_int64, c_int32, c_void_p, c_void_p]),
+    'mi355_mla_decode': (c_int, [
+        c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+        c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+        c_float, c_int32, c_void_p, c_size_t, c_void_p]),
+    'mi355_mla_decode_workspace_bytes': (c_size_t, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
     'mi355_slot_mapping': (c_int, [
         c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
 }

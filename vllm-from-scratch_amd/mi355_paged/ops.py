@@ -267,3 +267,51 @@ def slot_mapping(block_tables: torch.Tensor, starts: torch.Tensor, cu_tokens: to
                                     int(total_tokens), _stream(dev))
     _lib.check(rc, 'mi355_slot_mapping')
     return out
+
+
+def mla_decode(q: torch.Tensor, c_kv: torch.Tensor, k_rope: torch.Tensor, cos: torch.Tensor,
+               sin: torch.Tensor, context_lens: torch.Tensor, max_context: int, scale: float,
+               row_seq: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Latent-space MLA attention.
+
+    q [rows, H, R + P] (absorbed nope query | rotated rope query); c_kv [S_seqs, S, R] and
+    k_rope [S_seqs, S, P] (un-rotated) in q's 16-bit dtype; cos / sin [table_len, P] fp32;
+    context_lens [rows] int32; row_seq [rows] int32 or None.  Returns [rows, H, R] fp32.
+    """
+    dev = require_device(q, c_kv, k_rope, cos, sin, context_lens, row_seq)
+    lib = _lib.load()
+    if q.dim() != 3 or c_kv.dim() != 3 or k_rope.dim() != 3:
+        raise ValueError("q [rows,H,R+P], c_kv [seqs,S,R], k_rope [seqs,S,P] expected")
+    rows, H, DQ = q.shape
+    R, P = c_kv.shape[2], k_rope.shape[2]
+    if DQ != R + P:
+        raise ValueError(f"q last dim {DQ} != kv_lora_rank {R} + rope dim {P}")
+    if c_kv.dtype != q.dtype or k_rope.dtype != q.dtype:
+        raise TypeError("q, c_kv and k_rope must share a 16-bit dtype")
+    if q.stride(2) != 1 or q.stride(1) != DQ:
+        q = q.contiguous()
+    if c_kv.stride(2) != 1:
+        c_kv = c_kv.contiguous()
+    if k_rope.stride(2) != 1:
+        k_rope = k_rope.contiguous()
+    cos = cos.to(torch.float32).contiguous()
+    sin = sin.to(torch.float32).contiguous()
+    if cos.shape[-1] != P or tuple(sin.shape) != tuple(cos.shape):
+        raise ValueError("cos / sin must be [table_len, rope_dim]")
+    if context_lens.dtype != torch.int32 or (row_seq is not None and row_seq.dtype != torch.int32):
+        raise TypeError("context_lens / row_seq must be int32")
+    out = torch.empty((rows, H, R), dtype=torch.float32, device=dev)
+    code = dtype_code(q)
+    with torch.cuda.device(dev):
+        need = lib.mi355_mla_decode_workspace_bytes(rows, H, R, P, int(max_context), code)
+        ws, ws_bytes = _workspace(dev, need)
+        rc = lib.mi355_mla_decode(
+            out.data_ptr(), q.data_ptr(), _stride(q, 0),
+            c_kv.data_ptr(), _stride(c_kv, 0), _stride(c_kv, 1),
+            k_rope.data_ptr(), _stride(k_rope, 0), _stride(k_rope, 1),
+            cos.data_ptr(), sin.data_ptr(), cos.shape[0], context_lens.contiguous().data_ptr(),
+            row_seq.contiguous().data_ptr() if row_seq is not None else None,
+            rows, H, R, P, int(max_context), float(scale), code,
+            ws.data_ptr() if ws is not None else None, ws_bytes, _stream(dev))
+    _lib.check(rc, 'mi355_mla_decode')
+    return out
