@@ -81,3 +81,129 @@ def test_mla_causal_rows_of_one_sequence(ops, device):
                          torch.from_numpy(sin).to(device), torch.from_numpy(ctx).to(device), S, 0.2,
                          row_seq=torch.from_numpy(row_seq).to(device))
     np.testing.assert_allclose(out.cpu().numpy(), want, **TOL[torch.float16])
+
+
+# ------------------------------------------------------------------ drop-in mini_mla module
+@pytest.fixture(scope='module')
+def mla_mod(device):
+    import mini_mla
+    return mini_mla
+
+
+def test_module_matches_reference_outputs(mla_mod, device):
+    """Golden G9: same weights and inputs as the reference module, on host and device tensors."""
+    z = load_npz('g9_mla.npz')
+    meta = json.loads(str(z['meta']))
+    for ci, m in enumerate(meta['models']):
+        for dev in ('cpu', 'cuda'):
+            mod = mla_mod.MultiHeadLatentAttention(**m['config']).eval()
+            state = {k[len(f'm{ci}_w::'):]: torch.from_numpy(z[k].astype(np.float32))
+                     for k in z.files if k.startswith(f'm{ci}_w::')}
+            missing, unexpected = mod.load_state_dict(state, strict=False)
+            assert not unexpected and all('rotary' in k for k in missing)
+            mod = mod.to(dev)
+            for name in m['calls']:
+                pre = f'm{ci}_{name}_'
+                t = lambda a: torch.from_numpy(z[a]).to(dev)
+                past = (t(pre + 'past_c_kv'), t(pre + 'past_k_rope')) if pre + 'past_c_kv' in z.files else (None, None)
+                with torch.no_grad():
+                    out, nc, nr = mod(t(pre + 'x'), t(pre + 'pos'), *past)
+                np.testing.assert_allclose(out.cpu().numpy(), z[pre + 'out'], atol=5e-3, rtol=1e-2)
+                np.testing.assert_allclose(nc.cpu().numpy(), z[pre + 'new_c_kv'], atol=1e-5, rtol=1e-4)
+                np.testing.assert_allclose(nr.cpu().numpy(), z[pre + 'new_k_rope'], atol=1e-5, rtol=1e-4)
+    assert mla_mod.compare_kv_cache_size(num_heads=32, head_dim=128, kv_lora_rank=512, qk_rope_head_dim=64,
+                                         num_layers=32, seq_len=4096, batch_size=1) == tuple(meta['kv_size_mb'])
+
+
+class TestReferenceSuite:
+    """04_mla/test_mini_mla.py:10-170 restated against the drop-in module."""
+
+    def test_rotary(self, mla_mod):
+        rope = mla_mod.RotaryEmbedding(dim=64, max_seq_len=512)
+        for length in (1, 10, 128, 512, 600):
+            cos, sin = rope(length)
+            assert cos.shape == (length, 64) and sin.shape == (length, 64)
+            assert torch.allclose(cos ** 2 + sin ** 2, torch.ones_like(cos), atol=1e-5)
+        cos, sin = rope(1)
+        assert torch.allclose(cos[0], torch.ones(64), atol=1e-5) and torch.allclose(sin[0], torch.zeros(64), atol=1e-5)
+
+    def test_rotate_half(self, mla_mod):
+        x = torch.randn(3, 16)
+        assert mla_mod.rotate_half(torch.randn(4, 8, 64)).shape == (4, 8, 64)
+        assert torch.allclose(mla_mod.rotate_half(mla_mod.rotate_half(x)), -x, atol=1e-6)
+        q, k = torch.randn(1, 2, 5, 8), torch.randn(1, 2, 5, 8)
+        cos, sin = mla_mod.RotaryEmbedding(8)(5)
+        qr, kr = mla_mod.apply_rotary_emb(q, k, cos, sin)
+        assert torch.allclose(qr.norm(dim=-1), q.norm(dim=-1), atol=1e-5) and kr.shape == k.shape
+
+    @pytest.fixture
+    def small_mla(self, mla_mod):
+        return mla_mod.MultiHeadLatentAttention(hidden_size=128, num_heads=4, qk_nope_head_dim=16,
+                                                qk_rope_head_dim=8, kv_lora_rank=32, v_head_dim=16, max_seq_len=256)
+
+    def test_prefill_and_decode_shapes(self, small_mla):
+        B, T, D = 2, 16, 128
+        out, c_kv, k_rope = small_mla(torch.randn(B, T, D), torch.arange(T).unsqueeze(0).expand(B, -1))
+        assert out.shape == (B, T, D) and c_kv.shape == (B, T, 32) and k_rope.shape == (B, T, 8)
+        out, nc, nr = small_mla(torch.randn(B, 1, D), torch.tensor([[T]] * B), past_c_kv=c_kv, past_k_rope=k_rope)
+        assert out.shape == (B, 1, D) and nc.shape == (B, 1, 32) and nr.shape == (B, 1, 8)
+
+    def test_kv_cache_accumulation(self, small_mla, mla_mod):
+        _, c_kv, k_rope = small_mla(torch.randn(1, 5, 128), torch.arange(5).unsqueeze(0))
+        for step in range(3):
+            _, nc, nr = small_mla(torch.randn(1, 1, 128), torch.tensor([[5 + step]]), past_c_kv=c_kv,
+                                  past_k_rope=k_rope)
+            c_kv, k_rope = torch.cat([c_kv, nc], 1), torch.cat([k_rope, nr], 1)
+        assert c_kv.shape[1] == 8
+        cache = mla_mod.MLAKVCache(2, 16, 1, 32, 8, torch.device('cpu'), torch.float32)
+        cache.update(0, c_kv.detach(), k_rope.detach(), None)
+        got_c, got_r = cache.get(0, 1)
+        assert torch.equal(got_c[0], c_kv[0].detach()) and torch.equal(got_r[0], k_rope[0].detach())
+
+    def test_gradient_backprop(self, small_mla):
+        x = torch.randn(2, 8, 128, requires_grad=True)
+        out, _, _ = small_mla(x, torch.arange(8).unsqueeze(0).expand(2, -1))
+        out.sum().backward()
+        assert x.grad is not None and not torch.isnan(x.grad).any() and x.grad.abs().sum() > 0
+        assert small_mla.kv_b_proj.weight.grad is not None
+
+    def test_causal_mask_applied_prefill(self, small_mla):
+        small_mla.eval()
+        x = torch.randn(1, 4, 128)
+        pos = torch.arange(4).unsqueeze(0)
+        with torch.no_grad():
+            out1, _, _ = small_mla(x, pos)
+            x2 = x.clone()
+            x2[0, 2:] = torch.randn_like(x2[0, 2:])
+            out2, _, _ = small_mla(x2, pos)
+        assert torch.allclose(out1[0, :2], out2[0, :2], atol=1e-4)
+
+    def test_kv_size_helper(self, mla_mod):
+        mha, mla = mla_mod.compare_kv_cache_size(num_heads=32, head_dim=128, kv_lora_rank=512, qk_rope_head_dim=64,
+                                                 num_layers=32, seq_len=4096, batch_size=1)
+        assert mha / mla > 5
+        _, a = mla_mod.compare_kv_cache_size(seq_len=1024, num_heads=16, head_dim=64, kv_lora_rank=128,
+                                             qk_rope_head_dim=32, num_layers=8, batch_size=1)
+        _, b = mla_mod.compare_kv_cache_size(seq_len=4096, num_heads=16, head_dim=64, kv_lora_rank=128,
+                                             qk_rope_head_dim=32, num_layers=8, batch_size=1)
+        assert abs(b / a - 4.0) < 0.01
+
+
+def test_module_bf16_on_device_config4_like(mla_mod, device):
+    """A bf16 module with kv_lora_rank=512 / rope 64 decoding against a 1000-token cache: the module's
+    output equals the oracle's expanded-form forward on the same (bf16-rounded) weights."""
+    torch.manual_seed(3)
+    cfg = dict(hidden_size=256, num_heads=16, qk_nope_head_dim=128, qk_rope_head_dim=64, kv_lora_rank=512,
+               v_head_dim=128, max_seq_len=2048)
+    mod = mla_mod.MultiHeadLatentAttention(**cfg).to(torch.bfloat16).eval().to(device)
+    B, S = 2, 1000
+    past_c = (torch.randn(B, S, 512) * 0.5).to(torch.bfloat16).to(device)
+    past_r = (torch.randn(B, S, 64) * 0.5).to(torch.bfloat16).to(device)
+    x = (torch.randn(B, 1, 256) * 0.5).to(torch.bfloat16).to(device)
+    pos = torch.full((B, 1), S, device=device)
+    with torch.no_grad():
+        out, nc, nr = mod(x, pos, past_c, past_r)
+    w = {k: v.float().cpu().numpy() for k, v in mod.state_dict().items() if 'rotary' not in k}
+    want, _, _ = mo.mla_forward(w, cfg, x.float().cpu().numpy(), pos.cpu().numpy(), past_c.float().cpu().numpy(),
+                                past_r.float().cpu().numpy(), dtype=np.float64)
+    np.testing.assert_allclose(out.float().cpu().numpy(), want, atol=3e-2, rtol=5e-2)
