@@ -1,0 +1,40 @@
+"""Time mi355_mla_decode at the MLA configuration of BASELINE.json (kv_lora_rank=512, rope 64, ctx 4096).
+Usage: python tools/bench_mla.py [batch heads ctx]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'vllm-from-scratch_amd'))
+import torch
+from mi355_paged import ops
+
+B, H, S = ([int(x) for x in sys.argv[1:]] + [64, 16, 4096])[:3]
+R, P = 512, 64
+dev = torch.device('cuda', 0)
+g = torch.Generator(device=dev).manual_seed(0)
+sets = 3
+pools = [((torch.randn((B, S, R), generator=g, device=dev)).to(torch.bfloat16),
+          (torch.randn((B, S, P), generator=g, device=dev)).to(torch.bfloat16)) for _ in range(sets)]
+q = (torch.randn((B, H, R + P), generator=g, device=dev) * 0.3).to(torch.bfloat16)
+pos = torch.arange(S, device=dev, dtype=torch.float32)
+inv = 1.0 / (10000.0 ** (torch.arange(0, P, 2, device=dev).float() / P))
+ang = torch.outer(pos, inv)
+cos, sin = torch.cat([ang, ang], -1).cos(), torch.cat([ang, ang], -1).sin()
+ctx = torch.full((B,), S, dtype=torch.int32, device=dev)
+nbytes = B * S * (R + P) * 2 + B * H * (R + P) * 2 + B * H * R * 4
+flops = 2.0 * B * H * S * (R + P + R)
+for tgt in (None, 1024, 4096):
+    if tgt:
+        os.environ['MI355_MLA_TARGET_WGS'] = str(tgt)
+    n = 30
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for i in range(n + 5):
+        c, k = pools[i % sets]
+        if i >= 5:
+            ev[i - 5][0].record()
+        ops.mla_decode(q, c, k, cos, sin, ctx, S, 0.072)
+        if i >= 5:
+            ev[i - 5][1].record()
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in ev)[n // 2]
+    print(f"mla_decode B={B} H={H} ctx={S} R={R} P={P} target={tgt or 'default'}: {ms * 1e3:.1f} us  "
+          f"{nbytes / ms / 1e6:.0f} GB/s ({nbytes / ms / 1e6 / 80:.1f}% of 8 TB/s)  {flops / ms / 1e9:.1f} TFLOP/s", flush=True)

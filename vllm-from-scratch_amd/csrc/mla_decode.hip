@@ -32,7 +32,8 @@ typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int kTok = 16;        // tokens per step
+constexpr int kTok = 16;        // tokens per step (one-wave kernel)
+constexpr int kTok2 = 32;       // tokens per step (four-wave kernel)
 constexpr int kHeadTile = 16;   // heads per workgroup
 
 struct MlaParams {
@@ -224,6 +225,184 @@ __global__ void __launch_bounds__(kWave) mla_decode_kernel(const MlaParams p) {
   }
 }
 
+// Four-wave variant for kv_lora_rank >= 128.  The workgroup shares 32-token tiles through a
+// double-buffered LDS image (the next tile's global loads are issued into registers before the
+// current tile is reduced); every wave computes the full 32 x 16 score tile (cheap next to the
+// memory time) but owns only a quarter of the latent output dims, which keeps the accumulators
+// at R/4 per wave and lets 2 workgroups (8 waves) share a CU.
+template <class Tag, int R, int PP>
+__global__ void __launch_bounds__(256, 2) mla_decode_kernel_w4(const MlaParams p) {
+  constexpr int DK = R + PP;
+  constexpr int KS = DK / 32;
+  constexpr int OTW = R / 64;             // 16-dim output tiles per wave
+  constexpr int CPR = DK / 8;
+  constexpr int ROWB = DK * 2 + 16;
+  constexpr int NCH = kTok2 * CPR;
+  constexpr int NLOAD = (NCH + 255) / 256;
+  constexpr int MAXPAIR = 4;              // rope pairs per thread (P <= 64 -> half <= 32 -> 32 / 8 groups)
+  __shared__ __attribute__((aligned(16))) unsigned char tiles[2][kTok2 * ROWB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+  int bid = blockIdx.x;
+  const int ht = bid % p.n_ht;
+  bid /= p.n_ht;
+  const int sp = bid % p.nsplit;
+  const int row = bid / p.nsplit;
+  const int seq = p.row_seq ? p.row_seq[row] : row;
+  const int ctx = max(0, min(p.ctx[row], p.max_ctx));
+  const int t_begin = sp * p.tps;
+  if (p.nsplit > 1 && t_begin >= ctx) return;
+  const int t_end = min(ctx, t_begin + p.tps);
+  const int head = ht * kHeadTile + c;
+  const bool head_ok = head < p.H;
+
+  u32x4 qf[KS];
+  {
+    const char* qrow = static_cast<const char*>(p.q) + ((int64_t)row * p.q_stride_row + (int64_t)head * (R + p.P)) * 2;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int d = 32 * ks + 8 * g;
+      const bool ok = head_ok && (d < R || d - R < p.P);
+      qf[ks] = ok ? *reinterpret_cast<const u32x4*>(qrow + d * 2) : u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+  f32x4 o[OTW];
+#pragma unroll
+  for (int i = 0; i < OTW; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -1.0e30f, l_run = 0.f;
+
+  const char* ckv = static_cast<const char*>(p.ckv) + (int64_t)seq * p.ckv_stride_seq * 2;
+  const char* krope = static_cast<const char*>(p.krope) + (int64_t)seq * p.krope_stride_seq * 2;
+  const int half = p.P >> 1;
+  const int rtok = tid & 31, rgrp = tid >> 5;     // rope rotation: token of the tile, pair group 0..7
+  const int cstride = (int)p.ckv_stride_tok, rstride = (int)p.krope_stride_tok;   // host checks S * stride < 2^30
+
+  u32x4 stage[NLOAD];
+  float rc[MAXPAIR], rs[MAXPAIR];
+  auto issue_loads = [&](int t0) {
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      const int ch = tid + 256 * i;
+      const int tt = ch / CPR, dc = ch - tt * CPR;
+      const int tok = min(t0 + tt, t_end - 1);
+      const int d = dc * 8;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (ch < NCH) {
+        // 32-bit byte offsets from the (wave-uniform) sequence base keep the per-load address state small
+        if (d < R) v = load16<true>(ckv + (uint32_t)((tok * cstride + d) * 2));
+        else if (d - R < p.P) v = load16<true>(krope + (uint32_t)((tok * rstride + (d - R)) * 2));
+      }
+      stage[i] = v;
+    }
+    const int pos = min(min(t0 + rtok, t_end - 1), p.table_len - 1);
+#pragma unroll
+    for (int k = 0; k < MAXPAIR; ++k) {
+      const int i = rgrp + 8 * k;
+      rc[k] = i < half ? p.cos_t[(int64_t)pos * p.P + i] : 1.f;
+      rs[k] = i < half ? p.sin_t[(int64_t)pos * p.P + i] : 0.f;
+    }
+  };
+
+  const int ntiles = t_end > t_begin ? (t_end - t_begin + kTok2 - 1) / kTok2 : 0;
+  if (ntiles > 0) issue_loads(t_begin);
+  for (int t = 0; t < ntiles; ++t) {
+    const int t0 = t_begin + t * kTok2;
+    unsigned char* tile = tiles[t & 1];
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      const int ch = tid + 256 * i;
+      const int tt = ch / CPR, dc = ch - tt * CPR;
+      if (ch < NCH) *reinterpret_cast<u32x4*>(tile + tt * ROWB + dc * 16) = stage[i];
+    }
+    __syncthreads();
+    {   // rotate the rope part of the 32 rows in place (256 threads: token x 8 pair groups)
+      typename Tag::elem_t* kr = reinterpret_cast<typename Tag::elem_t*>(tile + rtok * ROWB + R * 2);
+#pragma unroll
+      for (int k = 0; k < MAXPAIR; ++k) {
+        const int i = rgrp + 8 * k;
+        if (i < half) {
+          const float lo = Tag::to_float(kr[i]), hi = Tag::to_float(kr[i + half]);
+          kr[i] = Mma16<Tag>::from_f(lo * rc[k] - hi * rs[k]);
+          kr[i + half] = Mma16<Tag>::from_f(hi * rc[k] + lo * rs[k]);
+        }
+      }
+    }
+    __syncthreads();
+    if (t + 1 < ntiles) issue_loads(t0 + kTok2);
+
+    f32x4 st[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      st[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(tile + (16 * u + c) * ROWB + (32 * ks + 8 * g) * 2);
+        st[u] = Mma16<Tag>::run(a, qf[ks], st[u]);
+      }
+    }
+    float s[8], mx = -__builtin_inff();
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float v = (t0 + 16 * u + 4 * g + j < t_end) ? st[u][j] * p.scale_log2e : -__builtin_inff();
+        s[4 * u + j] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float f = fast_exp2(m_run - m_new);
+    m_run = m_new;
+    float ps = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      s[j] = fast_exp2(s[j] - m_new);
+      ps += s[j];
+    }
+    ps += __shfl_xor(ps, 16);
+    ps += __shfl_xor(ps, 32);
+    l_run = l_run * f + ps;
+    if (!__all(f == 1.0f)) {
+#pragma unroll
+      for (int i = 0; i < OTW; ++i) o[i] *= f;
+    }
+    // k-slot (g, j): token 4g + j of the first 16 rows for j < 4, token 16 + 4g + (j - 4) for j >= 4
+    const u32x4 pb = {Mma16<Tag>::pack2(s[0], s[1]), Mma16<Tag>::pack2(s[2], s[3]),
+                      Mma16<Tag>::pack2(s[4], s[5]), Mma16<Tag>::pack2(s[6], s[7])};
+    const int qi = c >> 2, pi = c & 3;
+    const unsigned char* vrow = tile + (4 * g + qi) * ROWB + (4 * pi) * 2 + wave * OTW * 32;
+#pragma unroll
+    for (int i = 0; i < OTW; ++i) {
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) s16x4*)(vrow + i * 32));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) s16x4*)(vrow + i * 32 + 16 * ROWB));
+      const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
+      const u32x4 va = {lo2[0], lo2[1], hi2[0], hi2[1]};
+      o[i] = Mma16<Tag>::run(va, pb, o[i]);
+    }
+  }
+
+  if (!head_ok) return;
+  const int d_base = wave * OTW * 16 + 4 * g;       // lane holds O[head][d_base + 16*i + j]
+  if (p.nsplit == 1) {
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    float* dst = p.out + ((int64_t)row * p.H + head) * R + d_base;
+#pragma unroll
+    for (int i = 0; i < OTW; ++i) *reinterpret_cast<f32x4*>(dst + 16 * i) = o[i] * inv;
+  } else {
+    const int64_t rec = ((int64_t)row * p.H + head) * p.nsplit + sp;
+    float* dst = p.ws_acc + rec * R + d_base;
+#pragma unroll
+    for (int i = 0; i < OTW; ++i) *reinterpret_cast<f32x4*>(dst + 16 * i) = o[i];
+    if (wave == 0 && g == 0) {
+      p.ws_ml[rec * 2] = m_run;
+      p.ws_ml[rec * 2 + 1] = l_run;
+    }
+  }
+}
+
 template <int R>
 __global__ void __launch_bounds__(256) mla_merge_kernel(const MlaParams p) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -271,12 +450,14 @@ int mla_plan(int rows, int H, int R, int P, int max_context, int dtype, MlaPlan*
   pl.n_ht = (H + kHeadTile - 1) / kHeadTile;
   const int ctx = max_context > 0 ? max_context : 1;
   const int64_t base = (int64_t)rows * pl.n_ht;
-  const int target = env_int2("MI355_MLA_TARGET_WGS", 2048);   // 8 one-wave workgroups per CU
+  // one-wave kernel (R < 128): 8 workgroups per CU; four-wave kernel: 2 per CU
+  const int target = env_int2("MI355_MLA_TARGET_WGS", R >= 128 ? 512 : 2048);
   int64_t want = ceil_div64(target, base);
-  const int64_t most = ctx / 64 > 0 ? ctx / 64 : 1;             // at least 4 steps per workgroup
+  if (R >= 128 && want < 4) want = 4;                           // measured: 4 splits beat 2 at 256 rows x 4096 tokens
+  const int64_t most = ctx / 128 > 0 ? ctx / 128 : 1;           // at least 4 steps per workgroup
   if (want > most) want = most;
   if (want < 1) want = 1;
-  pl.tps = (int)(ceil_div64(ceil_div64(ctx, want), kTok) * kTok);
+  pl.tps = (int)(ceil_div64(ceil_div64(ctx, want), kTok2) * kTok2);
   pl.nsplit = (int)ceil_div64(ctx, pl.tps);
   pl.ws_bytes = pl.nsplit > 1 ? (size_t)rows * H * pl.nsplit * (R + 2) * sizeof(float) : 0;
   *out = pl;
@@ -286,8 +467,13 @@ int mla_plan(int rows, int H, int R, int P, int max_context, int dtype, MlaPlan*
 template <class Tag, int R>
 int launch_r(const MlaParams& p, hipStream_t s) {
   const int64_t grid = (int64_t)p.rows * p.nsplit * p.n_ht;
-  if (p.P <= 32) hipLaunchKernelGGL((mla_decode_kernel<Tag, R, 32>), dim3((unsigned)grid), dim3(kWave), 0, s, p);
-  else hipLaunchKernelGGL((mla_decode_kernel<Tag, R, 64>), dim3((unsigned)grid), dim3(kWave), 0, s, p);
+  if constexpr (R >= 128) {
+    if (p.P <= 32) hipLaunchKernelGGL((mla_decode_kernel_w4<Tag, R, 32>), dim3((unsigned)grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((mla_decode_kernel_w4<Tag, R, 64>), dim3((unsigned)grid), dim3(256), 0, s, p);
+  } else {
+    if (p.P <= 32) hipLaunchKernelGGL((mla_decode_kernel<Tag, R, 32>), dim3((unsigned)grid), dim3(kWave), 0, s, p);
+    else hipLaunchKernelGGL((mla_decode_kernel<Tag, R, 64>), dim3((unsigned)grid), dim3(kWave), 0, s, p);
+  }
   if (int rc = check_launch("mla_decode_kernel")) return rc;
   if (p.nsplit > 1) {
     const int64_t threads = (int64_t)p.rows * p.H * (R / 4);
@@ -339,6 +525,8 @@ extern "C" int mi355_mla_decode(float* out, const void* q, int64_t q_stride_row,
     return fail(MI355_EINVAL, "mla_decode: strides must keep rows 16-byte aligned");
   if (((uintptr_t)out | (uintptr_t)q | (uintptr_t)c_kv | (uintptr_t)k_rope) & 15)
     return fail(MI355_EINVAL, "mla_decode: tensors must be 16-byte aligned");
+  if ((int64_t)max_context * ckv_stride_tok >= (1LL << 30) || (int64_t)max_context * krope_stride_tok >= (1LL << 30))
+    return fail(MI355_EUNSUPPORTED, "mla_decode: one sequence's cache must span < 2^30 elements");
   if (pl.ws_bytes && (!workspace || workspace_bytes < pl.ws_bytes || ((uintptr_t)workspace & 15)))
     return fail(MI355_EWORKSPACE, "mla_decode: need %zu workspace bytes (16-B aligned), got %zu", pl.ws_bytes,
                 workspace ? workspace_bytes : (size_t)0);
