@@ -321,6 +321,10 @@ int elems_per_lane(int dtype) { return dtype == MI355_F32 ? 4 : 8; }
 #define MI355_DECODE_U 4
 #endif
 constexpr int kU = MI355_DECODE_U;  // 16-byte loads of K (and of V) per lane per pipeline step
+// With 8 query heads per wave the accumulators and scores take most of the register file;
+// a shallower step keeps the kernel free of scratch spills (a spill reload shares the
+// memory counter with the prefetch loads and would serialise them).
+constexpr int steps_for_group(int G) { return G >= 8 ? (kU > 2 ? 2 : kU) : kU; }
 
 // Launch geometry for a problem shape.  Deterministic in its arguments (plus the
 // MI355_PAGED_TARGET_WGS tuning variable), so the workspace query and the launch agree.
@@ -342,7 +346,7 @@ int make_plan(int B, int Hq, int Hkv, int D, int block_size, int max_context, in
   pl.G = gq >= 8 ? 8 : gq > 2 ? 4 : gq;  // 1, 2, 4 or 8 query heads per wave
   pl.qchunks = (gq + pl.G - 1) / pl.G;
   const int lpt = D / elems_per_lane(dtype);
-  const int ts = (kWave / lpt) * kU;
+  const int ts = (kWave / lpt) * steps_for_group(pl.G);
   const int quantum = pl.sub * ts;  // tokens one workgroup consumes per pipeline step
   const int ctx = max_context > 0 ? max_context : 1;
   const int64_t base_wgs = (int64_t)B * pl.hgroups * pl.qchunks;
@@ -374,7 +378,7 @@ int make_plan(int B, int Hq, int Hkv, int D, int block_size, int max_context, in
 template <class Tag, int D, int G>
 int launch_decode(const DecodeParams& p, const DecodePlan& pl, hipStream_t stream) {
   const int64_t grid = (int64_t)p.B * p.nsplit * p.hgroups * p.qchunks;
-  hipLaunchKernelGGL((paged_decode_kernel<Tag, D, G, kU, MI355_DECODE_NT != 0>), dim3((unsigned)grid),
+  hipLaunchKernelGGL((paged_decode_kernel<Tag, D, G, steps_for_group(G), MI355_DECODE_NT != 0>), dim3((unsigned)grid),
                      dim3(pl.nw * kWave), pl.lds_bytes, stream, p);
   if (int rc = check_launch("paged_decode_kernel")) return rc;
   if (p.nsplit > 1) {
