@@ -194,6 +194,49 @@ int mi355_mla_decode(float* out, const void* q, int64_t q_stride_row,
 size_t mi355_mla_decode_workspace_bytes(int32_t rows, int32_t H, int32_t R, int32_t P,
                                         int32_t max_context, int32_t dtype);
 
+/*
+ * Rotate-half RoPE applied in place to the query and key rows of T tokens, plus the write of
+ * the rotated key rows and of the value rows into the paged caches by flat slot id -- the
+ * three steps 05_mini_vllm/mini_vllm.py:415-427 (cos/sin gather by position, q/k rotation,
+ * indexed cache assignment) in one launch:
+ *
+ *   x'[i]       = x[i]       * cos[pos][i]       - x[i + D/2] * sin[pos][i]         (i < D/2)
+ *   x'[i + D/2] = x[i + D/2] * cos[pos][i + D/2] + x[i]       * sin[pos][i + D/2]
+ *
+ *   q [T, Hq, D], k / v [T, Hkv, D] with their own token strides (views into one fused
+ *   projection output are fine); cos_table / sin_table [table_len, D] in the same dtype;
+ *   positions [T] int64 (negative values index from the end of the table, as in torch);
+ *   slots [T] int64 or NULL (NULL: rotate only, nothing is written to the caches; a slot
+ *   outside [0, num_blocks*block_size) skips that token's cache write);
+ *   caches addressed by (block, head, row) strides as in mi355_paged_decode.
+ *   D must be a multiple of 16 (16-bit dtypes) or 8 (fp32).
+ */
+int mi355_rope_kv_write(void* q, void* k, const void* v, int64_t q_stride_tok, int64_t k_stride_tok,
+                        int64_t v_stride_tok, const void* cos_table, const void* sin_table,
+                        int32_t table_len, const int64_t* positions, const int64_t* slots,
+                        void* k_cache, void* v_cache, int32_t T, int32_t Hq, int32_t Hkv, int32_t D,
+                        int32_t block_size, int32_t num_blocks, int64_t kv_stride_block,
+                        int64_t kv_stride_head, int64_t kv_stride_tok, int32_t dtype, void* stream);
+
+/*
+ * RMS normalisation of T rows, optionally preceded by a residual add
+ * (RMSNorm.forward, 05_mini_vllm/mini_vllm.py:344-352, and the `x + attn(...)` of
+ * TransformerLayer.forward :511-514):
+ *   s = x + delta (when delta != NULL; s is also stored to sum_out [T, hidden]) else x
+ *   out[t] = weight * (s[t] / sqrt(mean(s[t]^2) + eps))            out [T, hidden] contiguous
+ * hidden must be a multiple of 8 (16-bit) / 4 (fp32) and at most 8192 / 4096.
+ */
+int mi355_rmsnorm(void* out, void* sum_out, const void* x, int64_t x_stride, const void* delta,
+                  int64_t delta_stride, const void* weight, float eps, int32_t T, int32_t hidden,
+                  int32_t dtype, void* stream);
+
+/*
+ * SwiGLU gating, out = silu(gate) * up elementwise over [T, width]
+ * (FFN.forward, 05_mini_vllm/mini_vllm.py:490-499); out is contiguous.
+ */
+int mi355_silu_mul(void* out, const void* gate, int64_t gate_stride, const void* up, int64_t up_stride,
+                   int32_t T, int32_t width, int32_t dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,3 +69,79 @@ def test_device_block_tables_many_requests_growth():
     got = tabs.gather(rows)
     for i, r in enumerate(reqs):
         assert got[i, :len(r.block_table)].tolist() == r.block_table
+
+
+# ------------------------------------------------------------------ decode-only scheduler path
+def _snapshot(sched):
+    alloc = sched.allocator
+    return dict(running=[(r.request_id, r.num_computed_tokens, list(r.output_token_ids), list(r.block_table),
+                          r.is_finished) for r in sched.running],
+                finished=[r.request_id for r in sched.finished],
+                free=list(alloc.free_blocks.items()), refs=list(alloc.ref_count))
+
+
+def _drive(fast, num_blocks, nreq, prompt_lens, max_new, eos_every=0, chunked=True):
+    """Run a scheduler to completion feeding deterministic 'sampled' tokens; with fast=True every
+    step first tries schedule_decode_only().  Returns the per-step trace and how often the
+    decode-only path served a step."""
+    from mini_vllm import BlockAllocator, Scheduler
+    sched = Scheduler(max_num_seqs=6, max_num_batched_tokens=24, block_size=4,
+                      allocator=BlockAllocator(num_blocks, 4), enable_chunked_prefill=chunked)
+    for i in range(nreq):
+        sched.add_request(Request(f"r{i}", list(range(1, prompt_lens[i % len(prompt_lens)] + 1)), max_new[i % len(max_new)]))
+    trace, served, step = [], 0, 0
+    while sched.has_unfinished and step < 400:
+        step += 1
+        batch = sched.schedule_decode_only() if fast else None
+        if batch is not None:
+            served += 1
+            feed = [(r.request_id, [r.output_token_ids[-1]], [r.num_computed_tokens], False,
+                     [r.block_table[r.num_computed_tokens // 4] * 4 + r.num_computed_tokens % 4]) for r in batch]
+            toks = [0 if eos_every and (step + j) % eos_every == 0 else 7 + (step + j) % 5 for j in range(len(batch))]
+            sched.update_decode_only(batch, toks)
+        else:
+            items = sched.schedule()
+            feed = [(it.request.request_id, list(it.tokens), list(it.positions), it.is_prefill, list(it.slot_mapping))
+                    for it in items]
+            toks = [0 if eos_every and (step + j) % eos_every == 0 else 7 + (step + j) % 5 for j in range(len(items))]
+            sched.update(items, toks)
+        trace.append((feed, _snapshot(sched)))
+    assert not sched.has_unfinished
+    return trace, served
+
+
+def test_decode_only_path_reproduces_the_general_scheduler():
+    """schedule_decode_only / update_decode_only leave requests, block tables and the allocator
+    (free-list order, refcounts) exactly as schedule / update do, step for step -- including runs
+    where blocks run short (the path declines and the general scheduler skips requests), requests
+    finish by EOS mid-batch, and new prompts keep arriving behind running decodes."""
+    cases = [dict(num_blocks=64, nreq=5, prompt_lens=[3, 9, 4], max_new=[9, 5, 14]),
+             dict(num_blocks=9, nreq=4, prompt_lens=[7, 5], max_new=[3, 12]),          # temporary block shortage
+             dict(num_blocks=64, nreq=9, prompt_lens=[2, 11, 6], max_new=[8, 3], eos_every=7),
+             dict(num_blocks=40, nreq=8, prompt_lens=[30, 3], max_new=[6], chunked=False)]
+    for kw in cases:
+        slow, none_served = _drive(False, **kw)
+        fast, served = _drive(True, **kw)
+        assert none_served == 0 and served > 0
+        assert len(slow) == len(fast)
+        for a, b in zip(slow, fast):
+            assert a == b
+
+
+def test_decode_only_path_declines_without_side_effects():
+    from mini_vllm import BlockAllocator, Scheduler
+    sched = Scheduler(4, 16, 4, BlockAllocator(3, 4))
+    assert sched.schedule_decode_only() is None                       # nothing running
+    a = Request("a", [1, 2, 3, 4], 8)
+    b = Request("b", [1, 2, 3, 4], 8)
+    sched.add_request(a)
+    sched.add_request(b)
+    assert sched.schedule_decode_only() is None                       # requests still waiting
+    items = sched.schedule()
+    sched.update(items, [5, 5])
+    assert [r.request_id for r in sched.running] == ["a", "b"] and sched.allocator.num_free == 1
+    before = _snapshot(sched)
+    assert sched.schedule_decode_only() is None                       # both need a block, one is free
+    assert _snapshot(sched) == before
+    sched.max_num_seqs = 1
+    assert sched.schedule_decode_only() is None                       # more running than the seq cap

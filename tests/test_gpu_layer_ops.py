@@ -1,0 +1,182 @@
+"""Fused layer steps around the attention kernels (RoPE + KV write, RMSNorm, SwiGLU gating)
+against the torch expressions of the reference model (05_mini_vllm/mini_vllm.py:344-357,
+:415-427, :490-499), and the HIP-graph decode step of the engine against its eager path.
+
+Tolerances: fp32 kernels follow the reference's operation order, atol 1e-6 (rtol 1e-5: the
+row mean is summed in a different order); 16-bit kernels compute in fp32 and round once, so
+they are compared with the fp32 expression on the same rounded inputs at 1 ulp of the output
+dtype (bf16 rtol 8e-3, fp16 rtol 1e-3)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: dict(atol=1e-6, rtol=1e-5), torch.bfloat16: dict(atol=1e-2, rtol=8e-3),
+       torch.float16: dict(atol=1e-3, rtol=1e-3)}
+
+
+@pytest.fixture(scope='module')
+def ops(device):
+    from mi355_paged import ops
+    return ops
+
+
+def rotate_half(x):
+    lo, hi = x.chunk(2, dim=-1)
+    return torch.cat((-hi, lo), dim=-1)
+
+
+def rope_tables(D, n, dtype, device):
+    inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2).float() / D))
+    ang = torch.outer(torch.arange(n).float(), inv)
+    tab = torch.cat([ang, ang], -1)
+    return tab.cos().to(dtype).to(device), tab.sin().to(dtype).to(device)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('T,Hq,Hkv,D,BS', [(1, 4, 4, 16, 8), (37, 8, 8, 64, 16), (5, 8, 2, 128, 4), (300, 4, 4, 32, 16)])
+def test_rope_kv_write_matches_torch(ops, device, dtype, T, Hq, Hkv, D, BS):
+    g = torch.Generator(device='cpu').manual_seed(T * 131 + D)
+    qkv = torch.randn(T, (Hq + 2 * Hkv) * D, generator=g).to(dtype).to(device)
+    q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
+    q, k, v = q.view(T, Hq, D), k.view(T, Hkv, D), v.view(T, Hkv, D)
+    cos, sin = rope_tables(D, 512, dtype, device)
+    pos = torch.randint(0, 512, (T,), generator=g).to(device)
+    NB = (T + BS - 1) // BS + 3
+    slots = torch.randperm(NB * BS, generator=g)[:T].to(device)
+    if T > 4:
+        slots[3] = -1                                          # skipped row
+    kc = torch.zeros(NB, BS, Hkv, D, dtype=dtype, device=device)
+    vc = torch.zeros_like(kc)
+    c, s = cos[pos].float().unsqueeze(1), sin[pos].float().unsqueeze(1)
+    want_q = q.float() * c + rotate_half(q.float()) * s
+    want_k = k.float() * c + rotate_half(k.float()) * s
+    v0 = v.clone()
+    ops.rope_kv_write(q, k, v, cos, sin, pos, slots, kc, vc, layout='NSHD')
+    tol = TOL[dtype]
+    torch.testing.assert_close(q.float(), want_q, **tol)
+    torch.testing.assert_close(k.float(), want_k, **tol)
+    assert torch.equal(v, v0)                                  # v is only read
+    flat_k, flat_v = kc.view(NB * BS, Hkv, D), vc.view(NB * BS, Hkv, D)
+    keep = slots >= 0
+    assert torch.equal(flat_k[slots[keep]], k[keep])            # the cache holds exactly the rotated rows
+    assert torch.equal(flat_v[slots[keep]], v[keep])
+    untouched = torch.ones(NB * BS, dtype=torch.bool, device=device)
+    untouched[slots[keep]] = False
+    assert not flat_k[untouched].any() and not flat_v[untouched].any()
+
+
+def test_rope_only_and_other_cache_layout(ops, device):
+    T, H, D, BS, NB = 9, 4, 32, 4, 5
+    q = torch.randn(T, H, D, device=device)
+    k = torch.randn(T, H, D, device=device)
+    v = torch.randn(T, H, D, device=device)
+    cos, sin = rope_tables(D, 64, torch.float32, device)
+    pos = torch.arange(T, device=device)
+    q0, k0 = q.clone(), k.clone()
+    ops.rope_kv_write(q, k, None, cos, sin, pos)               # rotate only
+    c, s = cos[pos].unsqueeze(1), sin[pos].unsqueeze(1)
+    torch.testing.assert_close(q, q0 * c + rotate_half(q0) * s, atol=1e-6, rtol=1e-6)
+    torch.testing.assert_close(k, k0 * c + rotate_half(k0) * s, atol=1e-6, rtol=1e-6)
+    # [blocks, heads, block_size, D] caches (the KVCachePool layout)
+    kc = torch.zeros(NB, H, BS, D, device=device)
+    vc = torch.zeros_like(kc)
+    slots = torch.arange(T, device=device) + 2
+    k1 = k.clone()
+    ops.rope_kv_write(q, k, v, cos, sin, pos, slots, kc, vc, layout='NHSD')
+    for t in range(T):
+        sl = int(slots[t])
+        assert torch.equal(kc[sl // BS, :, sl % BS], k[t]) and torch.equal(vc[sl // BS, :, sl % BS], v[t])
+    assert not torch.equal(k, k1)                              # rotated a second time in place
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('T,hidden', [(1, 64), (7, 512), (130, 1536), (3, 4096)])
+def test_rmsnorm_matches_torch(ops, device, dtype, T, hidden):
+    g = torch.Generator().manual_seed(hidden + T)
+    x = (torch.randn(T, hidden, generator=g) * 3).to(dtype).to(device)
+    d = torch.randn(T, hidden, generator=g).to(dtype).to(device)
+    w = (1 + 0.1 * torch.randn(hidden, generator=g)).to(dtype).to(device)
+    eps = 1e-6
+
+    def ref(t):
+        t = t.float()
+        return w.float() * (t / (t * t).mean(-1, keepdim=True).add(eps).sqrt())
+
+    tol = TOL[dtype]
+    torch.testing.assert_close(ops.rmsnorm(x, w, eps).float(), ref(x), **tol)
+    total, normed = ops.rmsnorm(x, w, eps, delta=d)
+    want_total = (x.float() + d.float()).to(dtype)
+    assert torch.equal(total, want_total)
+    torch.testing.assert_close(normed.float(), ref(want_total), **tol)
+    # strided input rows (a column slice of a wider activation)
+    wide = torch.randn(T, hidden * 2, generator=g).to(dtype).to(device)
+    torch.testing.assert_close(ops.rmsnorm(wide[:, :hidden], w, eps).float(), ref(wide[:, :hidden]), **tol)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+def test_silu_mul_matches_torch(ops, device, dtype):
+    g = torch.Generator().manual_seed(3)
+    both = (torch.randn(33, 2 * 1536, generator=g) * 4).to(dtype).to(device)
+    gate, up = both[:, :1536], both[:, 1536:]
+    want = torch.nn.functional.silu(gate.float()) * up.float()
+    torch.testing.assert_close(ops.silu_mul(gate, up).float(), want, **TOL[dtype])
+
+
+def test_layer_ops_reject_bad_arguments(ops, device):
+    x = torch.zeros(2, 12, device=device)
+    from mi355_paged._lib import Mi355Error
+    with pytest.raises(Mi355Error, match='multiple'):
+        ops.rmsnorm(torch.zeros(2, 6, device=device), torch.ones(6, device=device), 1e-6)
+    with pytest.raises(ValueError):
+        ops.silu_mul(x, x[:, :8])
+    with pytest.raises(RuntimeError, match='HIP device'):
+        ops.rmsnorm(torch.zeros(2, 8), torch.ones(8), 1e-6)
+
+
+# ------------------------------------------------------------------ engine: graph replay == eager
+def _run(mv, graphs, dtype, prompts, max_new, temperature=0.0, seed=0, **kw):
+    torch.manual_seed(7)
+    eng = mv.MiniVLLM(vocab_size=300, hidden_size=128, num_layers=2, num_heads=4, intermediate_size=256,
+                      num_kv_blocks=256, block_size=8, max_num_seqs=16, max_num_batched_tokens=256,
+                      device='cuda', dtype=dtype, decode_graphs=graphs, **kw)
+    for p, n in zip(prompts, max_new):
+        eng.add_request(p, max_new_tokens=n, temperature=temperature)
+    logits = []
+    forward = eng.model.forward_planned
+    eng.model.forward_planned = lambda *a, **k: logits.append(forward(*a, **k)) or logits[-1]
+    torch.manual_seed(seed)
+    outs, steps = {}, 0
+    while eng.scheduler.has_unfinished:
+        for rid, tok in eng.step():
+            outs.setdefault(rid, []).append(tok)
+        steps += 1
+    return eng, outs, steps
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_engine_graph_decode_equals_eager(device, dtype):
+    """Same weights and prompts: the engine that replays captured decode steps emits exactly the
+    token ids of the engine that runs every step eagerly (greedy), over a run in which the batch
+    shrinks as requests finish at different lengths and block tables grow across block borders."""
+    import mini_vllm as mv
+    rng = np.random.default_rng(11)
+    prompts = [[int(t) for t in rng.integers(1, 300, size=int(n))] for n in (5, 17, 9, 30, 2, 12, 8, 21, 3, 15, 6)]
+    max_new = [12, 30, 7, 19, 25, 4, 16, 9, 30, 11, 22]
+    eager, out_e, steps_e = _run(mv, False, dtype, prompts, max_new)
+    graph, out_g, steps_g = _run(mv, True, dtype, prompts, max_new)
+    assert not eager._graphs and len(graph._graphs) >= 2         # several batch-size buckets were captured
+    assert steps_e == steps_g
+    assert out_e == out_g
+    assert graph.allocator.num_free == 256 and eager.allocator.num_free == 256
+    assert [r.request_id for r in graph.scheduler.finished] == [r.request_id for r in eager.scheduler.finished]
+
+
+def test_engine_graph_decode_stochastic_rows_repeat(device):
+    """Sampling after a replayed step draws from the seeded generator like the eager path."""
+    import mini_vllm as mv
+    prompts = [[3, 4, 5], [9, 8, 7, 6], [1, 2]]
+    _, a, _ = _run(mv, True, torch.float32, prompts, [10, 10, 10], temperature=0.9, seed=5)
+    _, b, _ = _run(mv, False, torch.float32, prompts, [10, 10, 10], temperature=0.9, seed=5)
+    assert a == b

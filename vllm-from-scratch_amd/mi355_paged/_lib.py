@@ -41,6 +41,15 @@ SIGNATURES = {
     'mi355_mla_decode_workspace_bytes': (c_size_t, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
     'mi355_slot_mapping': (c_int, [
         c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    'mi355_rope_kv_write': (c_int, [
+        c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int32, c_void_p,
+        c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+        c_int64, c_int64, c_int64, c_int32, c_void_p]),
+    'mi355_rmsnorm': (c_int, [
+        c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_float, c_int32, c_int32,
+        c_int32, c_void_p]),
+    'mi355_silu_mul': (c_int, [
+        c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p]),
 }
 
 _lib = None

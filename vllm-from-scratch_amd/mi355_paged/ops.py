@@ -315,3 +315,104 @@ def mla_decode(q: torch.Tensor, c_kv: torch.Tensor, k_rope: torch.Tensor, cos: t
             ws.data_ptr() if ws is not None else None, ws_bytes, _stream(dev))
     _lib.check(rc, 'mi355_mla_decode')
     return out
+
+
+def _head_rows(t: torch.Tensor) -> torch.Tensor:
+    """[T, H, D] with contiguous head rows packed D apart (any token stride)."""
+    if t.dim() != 3 or t.stride(2) != 1 or (t.shape[1] != 1 and t.stride(1) != t.shape[2]):
+        raise ValueError("expected [T, H, D] with heads packed D apart and contiguous head rows")
+    return t
+
+
+def rope_kv_write(q: torch.Tensor, k: torch.Tensor, v: Optional[torch.Tensor], cos_table: torch.Tensor,
+                  sin_table: torch.Tensor, positions: torch.Tensor, slots: Optional[torch.Tensor] = None,
+                  k_cache: Optional[torch.Tensor] = None, v_cache: Optional[torch.Tensor] = None,
+                  layout: str = 'NSHD') -> None:
+    """Rotate q [T, Hq, D] and k [T, Hkv, D] IN PLACE (rotate-half RoPE with the table rows
+    picked by `positions`) and, when `slots` is given, write the rotated k and v [T, Hkv, D]
+    into the paged caches at those slots.  q / k / v may be views into one projection output."""
+    dev = require_device(q, k, v, cos_table, sin_table, positions, slots, k_cache, v_cache)
+    lib = _lib.load()
+    q, k = _head_rows(q), _head_rows(k)
+    T, Hq, D = q.shape
+    Hkv = k.shape[1]
+    if k.shape[0] != T or k.shape[2] != D or k.dtype != q.dtype:
+        raise ValueError("q and k must agree in token count, head_dim and dtype")
+    if cos_table.dtype != q.dtype or sin_table.dtype != q.dtype:
+        raise TypeError("cos / sin tables must have the dtype of q")
+    if cos_table.dim() != 2 or cos_table.shape[1] != D or tuple(sin_table.shape) != tuple(cos_table.shape) \
+            or not cos_table.is_contiguous() or not sin_table.is_contiguous():
+        raise ValueError("cos / sin tables must be contiguous [table_len, head_dim]")
+    if positions.dtype != torch.int64 or positions.numel() != T:
+        raise TypeError("positions must be int64 [T]")
+    positions = positions.contiguous()
+    geo = dict(block_size=0, num_blocks=0, s_block=0, s_head=0, s_tok=0)
+    v_stride = 0
+    if slots is not None:
+        if v is None or k_cache is None or v_cache is None:
+            raise ValueError("slots given without v / caches")
+        v = _head_rows(v)
+        if tuple(v.shape) != tuple(k.shape) or v.dtype != q.dtype or k_cache.dtype != q.dtype:
+            raise ValueError("v must match k; caches must match the dtype of q")
+        geo = _kv_geometry(k_cache, layout)
+        if tuple(v_cache.shape) != tuple(k_cache.shape) or _kv_geometry(v_cache, layout) != geo:
+            raise ValueError("k_cache and v_cache must share shape and strides")
+        if geo['heads'] != Hkv or geo['head_dim'] != D:
+            raise ValueError("cache heads / head_dim differ from k")
+        if slots.dtype != torch.int64 or slots.numel() != T:
+            raise TypeError("slots must be int64 [T]")
+        slots = slots.contiguous()
+        v_stride = _stride(v, 0)
+    with torch.cuda.device(dev):
+        rc = lib.mi355_rope_kv_write(
+            q.data_ptr(), k.data_ptr(), v.data_ptr() if slots is not None else None,
+            _stride(q, 0), _stride(k, 0), v_stride, cos_table.data_ptr(), sin_table.data_ptr(),
+            cos_table.shape[0], positions.data_ptr(), slots.data_ptr() if slots is not None else None,
+            k_cache.data_ptr() if slots is not None else None, v_cache.data_ptr() if slots is not None else None,
+            T, Hq, Hkv, D, geo['block_size'], geo['num_blocks'], geo['s_block'], geo['s_head'], geo['s_tok'],
+            dtype_code(q), _stream(dev))
+    _lib.check(rc, 'mi355_rope_kv_write')
+
+
+RMSNORM_MAX_HIDDEN = {torch.float32: 4096, torch.bfloat16: 8192, torch.float16: 8192}
+
+
+def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float, delta: Optional[torch.Tensor] = None):
+    """weight * (s / sqrt(mean(s^2) + eps)) per row of s = x (+ delta).  x, delta [T, hidden].
+    Returns the normalised rows, or (x + delta, normalised rows) when delta is given."""
+    dev = require_device(x, weight, delta)
+    lib = _lib.load()
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("x must be [T, hidden] with contiguous rows")
+    T, hidden = x.shape
+    if weight.dtype != x.dtype or weight.numel() != hidden or not weight.is_contiguous():
+        raise ValueError("weight must be a contiguous [hidden] tensor of x's dtype")
+    out = torch.empty((T, hidden), dtype=x.dtype, device=dev)
+    total = None
+    if delta is not None:
+        if tuple(delta.shape) != (T, hidden) or delta.dtype != x.dtype or delta.stride(1) != 1:
+            raise ValueError("delta must match x")
+        total = torch.empty((T, hidden), dtype=x.dtype, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.mi355_rmsnorm(out.data_ptr(), total.data_ptr() if total is not None else None, x.data_ptr(),
+                               _stride(x, 0), delta.data_ptr() if delta is not None else None,
+                               _stride(delta, 0) if delta is not None else 0, weight.data_ptr(), float(eps),
+                               T, hidden, dtype_code(x), _stream(dev))
+    _lib.check(rc, 'mi355_rmsnorm')
+    return out if delta is None else (total, out)
+
+
+def silu_mul(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+    """silu(gate) * up over [T, width] (rows may be strided views of one projection output)."""
+    dev = require_device(gate, up)
+    lib = _lib.load()
+    if gate.dim() != 2 or tuple(up.shape) != tuple(gate.shape) or gate.stride(1) != 1 or up.stride(1) != 1 \
+            or up.dtype != gate.dtype:
+        raise ValueError("gate and up must be [T, width] of one dtype with contiguous rows")
+    T, width = gate.shape
+    out = torch.empty((T, width), dtype=gate.dtype, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.mi355_silu_mul(out.data_ptr(), gate.data_ptr(), _stride(gate, 0), up.data_ptr(), _stride(up, 0),
+                                T, width, dtype_code(gate), _stream(dev))
+    _lib.check(rc, 'mi355_silu_mul')
+    return out

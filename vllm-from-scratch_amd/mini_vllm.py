@@ -253,6 +253,49 @@ class Scheduler:
                 self.running = [r for r in self.running if r is not req]
                 self.finished.append(req)
 
+    def schedule_decode_only(self) -> Optional[List[Request]]:
+        """The outcome of schedule() for the steady state of generation, without building
+        ScheduledRequest objects: nothing waiting, every running request past its prompt, and
+        enough free blocks that no request would be skipped.  Returns the requests in batch
+        order (each feeds its last token at position num_computed_tokens) after growing their
+        block tables exactly as schedule() would, or None -- having changed nothing -- when any
+        precondition fails and schedule() must decide."""
+        running = self.running
+        n = len(running)
+        if self.waiting or n == 0 or n > self.max_num_seqs or n > self.max_num_batched_tokens:
+            return None
+        bs = self.block_size
+        short = 0
+        for req in running:
+            done = req.num_computed_tokens
+            if req.is_finished or done < len(req.prompt_token_ids) or not req.output_token_ids:
+                return None
+            lack = -(-(done + 1) // bs) - len(req.block_table)
+            if lack > 0:
+                short += lack
+        if short > self.allocator.num_free:
+            return None
+        if short:
+            for req in running:
+                self._ensure_blocks(req, 1)
+        return list(running)
+
+    def update_decode_only(self, batch: List[Request], next_token_ids: List[int]):
+        """update() for a batch produced by schedule_decode_only()."""
+        finished = []
+        for req, token in zip(batch, next_token_ids):
+            req.num_computed_tokens += 1
+            out = req.output_token_ids
+            out.append(token)
+            if len(out) >= req.max_new_tokens or token == 0:
+                req.is_finished = True
+                for block in req.block_table:
+                    self.allocator.free(block)
+                finished.append(req)
+        if finished:
+            self.running = [r for r in self.running if not r.is_finished]
+            self.finished.extend(finished)
+
     @property
     def has_unfinished(self) -> bool:
         return bool(self.waiting or self.running)
@@ -426,16 +469,18 @@ def _compute_device(t: torch.Tensor) -> torch.device:
 
 def paged_attention_step(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, k_cache: torch.Tensor,
                          v_cache: torch.Tensor, slot_mapping: torch.Tensor, plan: AttnPlan,
-                         scale: float) -> torch.Tensor:
+                         scale: float, kv_written: bool = False) -> torch.Tensor:
     """KV write + attention for one layer of one step.  q, k, v: [T, H, D]; caches
-    [blocks, block_size, H, D].  Returns [T, H, D] on q's device."""
+    [blocks, block_size, H, D].  Returns [T, H, D] on q's device.  kv_written: the caller has
+    already put k and v into the caches (fused RoPE + write), only attention is left."""
     home = q.device
     dev = _compute_device(k_cache)
     staged = not k_cache.is_cuda
     kc = k_cache.to(dev) if staged else k_cache
     vc = v_cache.to(dev) if staged else v_cache
     q, k, v = q.to(dev), k.to(device=dev, dtype=kc.dtype), v.to(device=dev, dtype=kc.dtype)
-    ops.kv_write_slots(kc, vc, k, v, slot_mapping.to(dev), layout='NSHD')
+    if not kv_written:
+        ops.kv_write_slots(kc, vc, k, v, slot_mapping.to(dev), layout='NSHD')
     if staged:
         k_cache.copy_(kc)
         v_cache.copy_(vc)
@@ -466,15 +511,43 @@ def paged_attention_step(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, k_ca
 # model
 # ---------------------------------------------------------------------------
 
+def _kernel_rows(x: torch.Tensor, *params: torch.Tensor) -> bool:
+    """True when a [T, width] activation can go through the fused elementwise kernels: it
+    lives on the HIP device in a supported dtype shared by the given parameters, rows are
+    16-byte aligned, and nothing needs autograd (the kernels are inference-only)."""
+    if not x.is_cuda or x.dim() != 2 or x.dtype not in ops.RMSNORM_MAX_HIDDEN:
+        return False
+    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
+        return False
+    per16 = 16 // x.element_size()
+    return (x.stride(1) == 1 and x.shape[1] % per16 == 0 and x.stride(0) % per16 == 0
+            and all(p.dtype == x.dtype and p.device == x.device for p in params))
+
+
 class RMSNorm(nn.Module):
+    """weight * x / sqrt(mean(x^2) + eps) (05_mini_vllm/mini_vllm.py:344-352); one kernel
+    launch for device-resident rows, the torch expression otherwise."""
+
     def __init__(self, dim: int, eps: float = 1e-6):
         super().__init__()
         self.weight = nn.Parameter(torch.ones(dim))
         self.eps = eps
 
+    def fusable(self, x: torch.Tensor) -> bool:
+        return _kernel_rows(x, self.weight) and x.shape[1] <= ops.RMSNORM_MAX_HIDDEN[x.dtype]
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.fusable(x):
+            return ops.rmsnorm(x, self.weight, self.eps)
         rms = (x * x).mean(dim=-1, keepdim=True).add(self.eps).sqrt()
         return self.weight * (x / rms)
+
+    def add_forward(self, x: torch.Tensor, delta: torch.Tensor):
+        """(x + delta, norm(x + delta)) -- the residual add fused into the normalisation."""
+        if self.fusable(x) and _kernel_rows(delta) and delta.dtype == x.dtype:
+            return ops.rmsnorm(x, self.weight, self.eps, delta=delta)
+        total = x + delta
+        return total, self.forward(total)
 
 
 def rotate_half(x: torch.Tensor) -> torch.Tensor:
@@ -517,13 +590,22 @@ class SelfAttention(nn.Module):
         T, H, D = x.shape[0], self.num_heads, self.head_dim
         if plan is None:   # called the reference's way: no block tables -> reference semantics
             plan = build_attn_plan(positions.tolist(), seq_lens, is_prefill, None, _compute_device(kv_cache[0]))
-        q, k, v = (t.reshape(T, H, D) for t in self.qkv(x).chunk(3, dim=-1))
-        cos, sin = self.rope(positions)
-        cos, sin = cos.unsqueeze(1), sin.unsqueeze(1)
-        q = q * cos + rotate_half(q) * sin
-        k = k * cos + rotate_half(k) * sin
+        qkv = self.qkv(x)
+        q, k, v = (t.view(T, H, D) for t in qkv.chunk(3, dim=-1))
         k_cache, v_cache = kv_cache
-        attn = paged_attention_step(q, k, v, k_cache, v_cache, slot_mapping, plan, self.scale)
+        cos_t, sin_t = self.rope.cos_cached, self.rope.sin_cached
+        per32 = 32 // x.element_size()      # the fused kernel moves two 16-byte pieces per half row
+        if (_kernel_rows(qkv, cos_t, sin_t) and k_cache.is_cuda and k_cache.dtype == x.dtype and D % per32 == 0
+                and positions.dtype == torch.int64 and slot_mapping.dtype == torch.int64):
+            # RoPE on q and k in place inside the projection output + cache write, one launch
+            ops.rope_kv_write(q, k, v, cos_t, sin_t, positions, slot_mapping, k_cache, v_cache, layout='NSHD')
+            attn = paged_attention_step(q, k, v, k_cache, v_cache, slot_mapping, plan, self.scale, kv_written=True)
+        else:
+            cos, sin = self.rope(positions)
+            cos, sin = cos.unsqueeze(1), sin.unsqueeze(1)
+            q = q * cos + rotate_half(q) * sin
+            k = k * cos + rotate_half(k) * sin
+            attn = paged_attention_step(q, k, v, k_cache, v_cache, slot_mapping, plan, self.scale)
         return self.out_proj(attn.reshape(plan.total_tokens, H * D).to(x.dtype))
 
 
@@ -537,7 +619,10 @@ class FFN(nn.Module):
         self.down = nn.Linear(intermediate_size, hidden_size, bias=False)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return self.down(F.silu(self.gate(x)) * self.up(x))
+        gate, up = self.gate(x), self.up(x)
+        if _kernel_rows(gate) and _kernel_rows(up):
+            return self.down(ops.silu_mul(gate, up))
+        return self.down(F.silu(gate) * up)
 
 
 class TransformerLayer(nn.Module):
@@ -549,8 +634,9 @@ class TransformerLayer(nn.Module):
         self.norm2 = RMSNorm(hidden_size)
 
     def forward(self, x, positions, kv_cache, slot_mapping, seq_lens, is_prefill, plan=None):
-        x = x + self.attn(self.norm1(x), positions, kv_cache, slot_mapping, seq_lens, is_prefill, plan)
-        return x + self.ffn(self.norm2(x))
+        attn = self.attn(self.norm1(x), positions, kv_cache, slot_mapping, seq_lens, is_prefill, plan)
+        x, normed = self.norm2.add_forward(x, attn)
+        return x + self.ffn(normed)
 
 
 class MiniTransformer(nn.Module):
@@ -593,15 +679,83 @@ class MiniTransformer(nn.Module):
             positions_host = positions.tolist()
         plan = build_attn_plan(positions_host, seq_lens, is_prefill, block_tables,
                                _compute_device(self.k_cache), reference_compat, device_tables, table_rows)
-        x = self.embedding(token_ids)
-        for i, layer in enumerate(self.layers):
-            x = layer(x, positions, (self.k_cache[i], self.v_cache[i]), slot_mapping, seq_lens, is_prefill, plan)
-        x = self.norm(x)
         last, offset = [], 0
         for n in seq_lens:
             offset += n
             last.append(offset - 1)
-        return self.lm_head(x[last])
+        return self.forward_planned(token_ids, positions, slot_mapping, plan, last, seq_lens, is_prefill)
+
+    def forward_planned(self, token_ids: torch.Tensor, positions: torch.Tensor, slot_mapping: torch.Tensor,
+                        plan: AttnPlan, last: Optional[List[int]] = None, seq_lens: Optional[List[int]] = None,
+                        is_prefill: Optional[List[bool]] = None) -> torch.Tensor:
+        """The layer stack for an already planned step; `last` = flattened index of each
+        request's final token (None: every token is one, as in a pure decode step)."""
+        x = self.embedding(token_ids)
+        for i, layer in enumerate(self.layers):
+            x = layer(x, positions, (self.k_cache[i], self.v_cache[i]), slot_mapping, seq_lens, is_prefill, plan)
+        if last is not None and len(last) != x.shape[0]:
+            x = x[last]
+        return self.lm_head(self.norm(x))
+
+
+# ---------------------------------------------------------------------------
+# captured decode step
+# ---------------------------------------------------------------------------
+
+class DecodeStepGraph:
+    """A pure-decode model step recorded once as a HIP graph and replayed per step.
+
+    The step's only per-call inputs are three int32 vectors (last token, position and
+    block-table row of every sequence) staged through one pinned host buffer; slot mapping,
+    context lengths and the gathered block tables are derived on the device inside the graph,
+    so a replay costs one small host-to-device copy and one graph launch.  The batch is padded
+    to `rows` sequences (padding rows have position -1: context 0, no cache write) and the
+    attention launch is sized for contexts up to `max_context`.
+    """
+
+    def __init__(self, model: "MiniTransformer", tables: DeviceBlockTables, rows: int, max_context: int):
+        dev = tables.device
+        self.model, self.tables, self.rows, self.max_context = model, tables, rows, max_context
+        self.table_tensor = tables.tables            # the graph is bound to this storage
+        self.host = torch.zeros((3, rows), dtype=torch.int32).pin_memory()
+        self.host_np = self.host.numpy()
+        self.dev = torch.zeros((3, rows), dtype=torch.int32, device=dev)
+        self.dev[1].fill_(-1)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), torch.no_grad():      # warm-up: workspaces, GEMM plans
+            for _ in range(2):
+                self._body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.logits = self._body()
+
+    def _body(self) -> torch.Tensor:
+        bs = self.model.block_size
+        tok, pos, row = self.dev[0].long(), self.dev[1].long(), self.dev[2].long()
+        tables = self.table_tensor.index_select(0, row)
+        live = pos >= 0
+        block = tables.gather(1, (pos // bs).clamp(min=0, max=tables.shape[1] - 1).unsqueeze(1)).squeeze(1).long()
+        slots = torch.where(live, block * bs + pos % bs, torch.full_like(pos, -1))
+        plan = AttnPlan(total_tokens=self.rows, causal_index=None, cu_seqlens=None, causal_tokens=0,
+                        max_causal_len=0, paged_index=None, paged_tables=tables,
+                        paged_context=(self.dev[1] + 1), paged_rows=self.rows, max_context=self.max_context)
+        return self.model.forward_planned(tok, pos.clamp(min=0), slots, plan)
+
+    def run(self, tokens: Sequence[int], positions: Sequence[int], rows: Sequence[int]) -> torch.Tensor:
+        """Logits [len(tokens), vocab] (a view of the graph's output buffer, valid until the next run)."""
+        n = len(tokens)
+        buf = self.host_np
+        buf[0, :n] = tokens
+        buf[1, :n] = positions
+        buf[2, :n] = rows
+        buf[0, n:] = 0
+        buf[1, n:] = -1
+        buf[2, n:] = 0
+        self.dev.copy_(self.host, non_blocking=True)
+        self.graph.replay()
+        return self.logits[:n]
 
 
 # ---------------------------------------------------------------------------
@@ -661,9 +815,13 @@ class MiniVLLM:
                  num_heads: int = 4, intermediate_size: int = 512, num_kv_blocks: int = 256,
                  block_size: int = 16, max_num_seqs: int = 8, max_num_batched_tokens: int = 1024,
                  enable_chunked_prefill: bool = True, device: str = 'cpu',
-                 reference_compat: bool = False, dtype: Optional[torch.dtype] = None):
+                 reference_compat: bool = False, dtype: Optional[torch.dtype] = None,
+                 decode_graphs: bool = True):
         self.device = torch.device(device)
         self.reference_compat = reference_compat
+        # replay pure-decode steps as HIP graphs (device-resident engines only)
+        self.decode_graphs = decode_graphs and self.device.type == 'cuda' and not reference_compat
+        self._graphs: "OrderedDict[tuple, DecodeStepGraph]" = OrderedDict()
         self.allocator = BlockAllocator(num_kv_blocks, block_size)
         self.scheduler = Scheduler(max_num_seqs=max_num_seqs,
                                    max_num_batched_tokens=max_num_batched_tokens,
@@ -688,9 +846,53 @@ class MiniVLLM:
                                            top_p=top_p))
         return req_id
 
+    MAX_GRAPHS = 12     # captured decode steps kept per engine (least recently used is dropped)
+
+    def _decode_graph(self, nseq: int, max_context: int) -> DecodeStepGraph:
+        """The captured step serving `nseq` sequences with contexts up to `max_context`:
+        batch padded to 8 / a multiple of 16, context bound rounded up to a multiple of 256."""
+        rows = 8 if nseq <= 8 else -(-nseq // 16) * 16
+        bound = -(-max_context // 256) * 256
+        tables = self._device_tables
+        key = (rows, bound, tables.tables.data_ptr(), tables.tables.shape[1], self.model.k_cache.data_ptr())
+        graph = self._graphs.get(key)
+        if graph is None:
+            for stale in [k for k in self._graphs if k[2:] != key[2:]]:
+                del self._graphs[stale]          # block tables or KV buffers were reallocated
+            while len(self._graphs) >= self.MAX_GRAPHS:
+                self._graphs.popitem(last=False)
+            graph = self._graphs[key] = DecodeStepGraph(self.model, tables, rows, bound)
+        else:
+            self._graphs.move_to_end(key)
+        return graph
+
+    def _step_decode_only(self):
+        """A step in which every running request decodes one token, served by a captured
+        graph; None when the scheduler state needs the general path."""
+        batch = self.scheduler.schedule_decode_only()
+        if batch is None:
+            return None
+        if self._device_tables is None:
+            self._device_tables = DeviceBlockTables(_compute_device(self.model.k_cache),
+                                                    rows=max(8, self.scheduler.max_num_seqs))
+        rows = self._device_tables.sync(batch)
+        tokens = [r.output_token_ids[-1] for r in batch]
+        positions = [r.num_computed_tokens for r in batch]
+        logits = self._decode_graph(len(batch), max(positions) + 1).run(tokens, positions, rows)
+        next_tokens = self.sampler.sample(logits, batch)
+        self.scheduler.update_decode_only(batch, next_tokens)
+        for req in batch:
+            if req.is_finished:
+                self._device_tables.release(req.request_id)
+        return [(req.request_id, tok) for req, tok in zip(batch, next_tokens)]
+
     def step(self):
         """One engine step; returns [(request_id, new_token)] for every request that
         produced a token (decode steps and the final chunk of a prompt)."""
+        if self.decode_graphs:
+            fast = self._step_decode_only()
+            if fast is not None:
+                return fast
         scheduled = self.scheduler.schedule()
         if not scheduled:
             return []
