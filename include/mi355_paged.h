@@ -237,6 +237,24 @@ int mi355_rmsnorm(void* out, void* sum_out, const void* x, int64_t x_stride, con
 int mi355_silu_mul(void* out, const void* gate, int64_t gate_stride, const void* up, int64_t up_stride,
                    int32_t T, int32_t width, int32_t dtype, void* stream);
 
+/*
+ * Device-side inputs of a pure decode step (every sequence feeds one token), replacing the
+ * host flattening of MiniVLLM.step (05_mini_vllm/mini_vllm.py:722-739) and
+ * Scheduler._compute_slot_mapping (:209-219) for that case.  The host uploads one int32
+ * array packed[3][rows] = (last token, position, row of the sequence in table_pool); for
+ * every r the kernel writes
+ *   token_ids[r] = token, positions[r] = max(position, 0)                         (int64)
+ *   context_lens[r] = position + 1                                                (int32)
+ *   block_tables[r][:] = table_pool[row][:]                                       (int32, [rows, width])
+ *   slots[r] = table_pool[row][position / block_size] * block_size + position % block_size
+ * A negative position marks a padding row: context 0 and slot -1 (no cache write).
+ * table_pool is [pool_rows, width] int32.
+ */
+int mi355_decode_step_inputs(int64_t* token_ids, int64_t* positions, int64_t* slots,
+                             int32_t* context_lens, int32_t* block_tables, const int32_t* packed,
+                             const int32_t* table_pool, int32_t rows, int32_t pool_rows, int32_t width,
+                             int32_t block_size, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -348,7 +348,7 @@ def test_engine_mixed_batch_128_attention_parity(mv, device, monkeypatch):
     H, D, BS = 8, 64, 16
     eng = mv.MiniVLLM(vocab_size=500, hidden_size=H * D, num_layers=2, num_heads=H, intermediate_size=256,
                       num_kv_blocks=1200, block_size=BS, max_num_seqs=128, max_num_batched_tokens=1024,
-                      enable_chunked_prefill=True, device='cuda')
+                      enable_chunked_prefill=True, device='cuda', decode_graphs=False)   # every step audited eagerly
     rng = np.random.default_rng(3)
     prompts = [[int(t) for t in rng.integers(1, 500, size=int(rng.integers(4, 120)))] for _ in range(128)]
     for p in prompts:
@@ -357,8 +357,8 @@ def test_engine_mixed_batch_128_attention_parity(mv, device, monkeypatch):
     real = mv.paged_attention_step
     checked = {'tokens': 0, 'steps': 0, 'kinds': set()}
 
-    def spy(q, k, v, k_cache, v_cache, slot_mapping, plan, scale):
-        out = real(q, k, v, k_cache, v_cache, slot_mapping, plan, scale)
+    def spy(q, k, v, k_cache, v_cache, slot_mapping, plan, scale, **kw):
+        out = real(q, k, v, k_cache, v_cache, slot_mapping, plan, scale, **kw)
         if k_cache.data_ptr() != eng.model.k_cache[0].data_ptr():
             return out                                              # only layer 0 is audited
         kc = k_cache.permute(0, 2, 1, 3).float().cpu().numpy()      # -> [NB, H, BS, D]

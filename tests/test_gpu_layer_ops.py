@@ -180,3 +180,27 @@ def test_engine_graph_decode_stochastic_rows_repeat(device):
     _, a, _ = _run(mv, True, torch.float32, prompts, [10, 10, 10], temperature=0.9, seed=5)
     _, b, _ = _run(mv, False, torch.float32, prompts, [10, 10, 10], temperature=0.9, seed=5)
     assert a == b
+
+
+def test_decode_step_inputs_bit_exact(ops, device):
+    """Slot mapping, context lengths and gathered block tables of a decode batch, integer-exact
+    against the host formulas (05_mini_vllm/mini_vllm.py:209-219), padding rows included."""
+    rng = np.random.default_rng(5)
+    pool_rows, width, BS, rows = 40, 9, 16, 24
+    pool = rng.integers(0, 5000, size=(pool_rows, width)).astype(np.int32)
+    tok = rng.integers(0, 32000, size=rows).astype(np.int32)
+    pos = rng.integers(0, width * BS, size=rows).astype(np.int32)
+    row = rng.integers(0, pool_rows, size=rows).astype(np.int32)
+    pos[[3, 17]] = -1                                            # padding rows
+    packed = torch.from_numpy(np.stack([tok, pos, row])).to(device)
+    t, p, s, c, bt = ops.decode_step_inputs(packed, torch.from_numpy(pool).to(device), BS)
+    assert t.tolist() == tok.tolist()
+    assert p.tolist() == np.maximum(pos, 0).tolist()
+    assert c.tolist() == (pos + 1).clip(min=0).tolist()
+    assert bt.cpu().numpy().tolist() == pool[row].tolist()
+    want = [-1 if q < 0 else int(pool[r][q // BS]) * BS + q % BS for q, r in zip(pos.tolist(), row.tolist())]
+    assert s.tolist() == want
+    # a block size that is not a power of two; a position past the table's last block gets no slot
+    t, p, s, c, bt = ops.decode_step_inputs(packed, torch.from_numpy(pool).to(device), 12)
+    assert s.tolist() == [-1 if q < 0 or q // 12 >= width else int(pool[r][q // 12]) * 12 + q % 12
+                          for q, r in zip(pos.tolist(), row.tolist())]

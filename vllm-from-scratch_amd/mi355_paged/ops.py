@@ -416,3 +416,24 @@ def silu_mul(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
                                 T, width, dtype_code(gate), _stream(dev))
     _lib.check(rc, 'mi355_silu_mul')
     return out
+
+
+def decode_step_inputs(packed: torch.Tensor, table_pool: torch.Tensor, block_size: int):
+    """packed int32 [3, rows] = (token, position, pool row) -> (token_ids i64 [rows], positions i64
+    [rows], slots i64 [rows], context_lens i32 [rows], block_tables i32 [rows, width])."""
+    dev = require_device(packed, table_pool)
+    lib = _lib.load()
+    if packed.dtype != torch.int32 or packed.dim() != 2 or packed.shape[0] != 3 or not packed.is_contiguous():
+        raise ValueError("packed must be a contiguous int32 [3, rows] tensor")
+    if table_pool.dtype != torch.int32 or table_pool.dim() != 2 or not table_pool.is_contiguous():
+        raise ValueError("table_pool must be a contiguous int32 [pool_rows, width] tensor")
+    rows, width = packed.shape[1], table_pool.shape[1]
+    i64 = torch.empty((3, rows), dtype=torch.int64, device=dev)
+    ctx = torch.empty((rows,), dtype=torch.int32, device=dev)
+    tables = torch.empty((rows, width), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.mi355_decode_step_inputs(i64[0].data_ptr(), i64[1].data_ptr(), i64[2].data_ptr(), ctx.data_ptr(),
+                                          tables.data_ptr(), packed.data_ptr(), table_pool.data_ptr(), rows,
+                                          table_pool.shape[0], width, int(block_size), _stream(dev))
+    _lib.check(rc, 'mi355_decode_step_inputs')
+    return i64[0], i64[1], i64[2], ctx, tables

@@ -732,16 +732,11 @@ class DecodeStepGraph:
             self.logits = self._body()
 
     def _body(self) -> torch.Tensor:
-        bs = self.model.block_size
-        tok, pos, row = self.dev[0].long(), self.dev[1].long(), self.dev[2].long()
-        tables = self.table_tensor.index_select(0, row)
-        live = pos >= 0
-        block = tables.gather(1, (pos // bs).clamp(min=0, max=tables.shape[1] - 1).unsqueeze(1)).squeeze(1).long()
-        slots = torch.where(live, block * bs + pos % bs, torch.full_like(pos, -1))
+        tok, pos, slots, ctx, tables = ops.decode_step_inputs(self.dev, self.table_tensor, self.model.block_size)
         plan = AttnPlan(total_tokens=self.rows, causal_index=None, cu_seqlens=None, causal_tokens=0,
-                        max_causal_len=0, paged_index=None, paged_tables=tables,
-                        paged_context=(self.dev[1] + 1), paged_rows=self.rows, max_context=self.max_context)
-        return self.model.forward_planned(tok, pos.clamp(min=0), slots, plan)
+                        max_causal_len=0, paged_index=None, paged_tables=tables, paged_context=ctx,
+                        paged_rows=self.rows, max_context=self.max_context)
+        return self.model.forward_planned(tok, pos, slots, plan)
 
     def run(self, tokens: Sequence[int], positions: Sequence[int], rows: Sequence[int]) -> torch.Tensor:
         """Logits [len(tokens), vocab] (a view of the graph's output buffer, valid until the next run)."""
@@ -846,12 +841,14 @@ class MiniVLLM:
                                            top_p=top_p))
         return req_id
 
-    MAX_GRAPHS = 12     # captured decode steps kept per engine (least recently used is dropped)
+    MAX_GRAPHS = 32     # captured decode steps kept per engine (least recently used is dropped)
 
     def _decode_graph(self, nseq: int, max_context: int) -> DecodeStepGraph:
-        """The captured step serving `nseq` sequences with contexts up to `max_context`:
-        batch padded to 8 / a multiple of 16, context bound rounded up to a multiple of 256."""
-        rows = 8 if nseq <= 8 else -(-nseq // 16) * 16
+        """The captured step serving `nseq` sequences with contexts up to `max_context`: batch
+        padded to 8, then to a multiple of 16 / 32 / 64 (up to 64 / 256 / beyond), context bound
+        rounded up to a multiple of 256."""
+        quantum = 8 if nseq <= 8 else 16 if nseq <= 64 else 32 if nseq <= 256 else 64
+        rows = -(-nseq // quantum) * quantum
         bound = -(-max_context // 256) * 256
         tables = self._device_tables
         key = (rows, bound, tables.tables.data_ptr(), tables.tables.shape[1], self.model.k_cache.data_ptr())
