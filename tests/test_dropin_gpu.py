@@ -397,3 +397,41 @@ def test_engine_mixed_batch_128_attention_parity(mv, device, monkeypatch):
     assert checked['tokens'] > 500 and checked['steps'] == steps
     assert max(len(s) for s in [r.output_token_ids for r in eng.scheduler.finished]) == 4
     assert eng.allocator.num_free == 1200
+
+
+# ------------------------------------------------------------------ prefix caching end to end
+def test_engine_prefix_caching_same_tokens_fewer_computed(mv, device):
+    """Requests sharing a long prompt prefix: with enable_prefix_caching the later ones start
+    after the cached blocks (attending to them through their block tables) and the engine emits
+    the same greedy token ids as without caching; first-token logits agree to fp32 GEMM noise."""
+    kw = dict(vocab_size=150, hidden_size=64, num_layers=2, num_heads=4, intermediate_size=128,
+              num_kv_blocks=128, block_size=8, max_num_seqs=4, max_num_batched_tokens=512, device='cuda')
+    rng = np.random.default_rng(9)
+    system = [int(t) for t in rng.integers(1, 150, size=43)]               # 5 full blocks + 3 tokens
+    prompts = [system + [int(t) for t in rng.integers(1, 150, size=n)] for n in (4, 9, 1, 14, 6)]
+    results = {}
+    for caching in (False, True):
+        torch.manual_seed(2)
+        eng = mv.MiniVLLM(**kw, enable_prefix_caching=caching)
+        logits = []
+        forward = eng.model.forward_planned
+        eng.model.forward_planned = lambda *a, _f=forward, _l=logits, **k: _l.append(_f(*a, **k)) or _l[-1]
+        outs = []
+        for p in prompts:                                                  # one after another: later ones can hit
+            rid = eng.add_request(p, max_new_tokens=6, temperature=0.0)
+            got = []
+            first = None
+            while eng.scheduler.has_unfinished:
+                for r, tok in eng.step():
+                    got.append(tok)
+                if first is None:
+                    first = logits[-1][0].float().cpu()
+            outs.append((got, first))
+        results[caching] = (outs, dict(eng.scheduler.prefix_stats), eng.allocator.num_free)
+    plain, cached = results[False], results[True]
+    assert [o[0] for o in plain[0]] == [o[0] for o in cached[0]]
+    for (_, a), (_, b) in zip(plain[0], cached[0]):
+        torch.testing.assert_close(a, b, atol=2e-4, rtol=1e-4)
+    assert plain[1]['cached_tokens'] == 0
+    assert cached[1]['requests'] == 5 and cached[1]['cached_tokens'] == 4 * 40   # 5 shared blocks x 4 later requests
+    assert plain[2] == cached[2] == 128

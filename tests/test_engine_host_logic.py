@@ -145,3 +145,103 @@ def test_decode_only_path_declines_without_side_effects():
     assert _snapshot(sched) == before
     sched.max_num_seqs = 1
     assert sched.schedule_decode_only() is None                       # more running than the seq cap
+
+
+# ------------------------------------------------------------------ prefix caching (host logic)
+def _prefix_sched(num_blocks=32, bs=4, budget=64, **kw):
+    from mini_vllm import BlockAllocator, Scheduler
+    return Scheduler(max_num_seqs=8, max_num_batched_tokens=budget, block_size=bs,
+                     allocator=BlockAllocator(num_blocks, bs), enable_prefix_caching=True, **kw)
+
+
+def test_prompt_block_hashes_chain():
+    from mini_vllm import prompt_block_hashes
+    a = prompt_block_hashes([1, 2, 3, 4, 5, 6, 7, 8, 9], 4)
+    assert len(a) == 2                                              # only full blocks
+    assert a == prompt_block_hashes([1, 2, 3, 4, 5, 6, 7, 8], 4)
+    b = prompt_block_hashes([9, 2, 3, 4, 5, 6, 7, 8], 4)
+    assert a[0] != b[0] and a[1] != b[1]                            # same 2nd block, different prefix
+    assert a[0] == hash((0, (1, 2, 3, 4), None))                    # the reference's formula, seed 0
+    assert prompt_block_hashes([1, 2, 3], 4) == []
+
+
+def test_prefix_cache_shares_prompt_blocks_between_requests():
+    sched = _prefix_sched()
+    shared = list(range(1, 13))                                     # 3 full blocks
+    a = Request("a", shared + [50, 51], 4)
+    sched.add_request(a)
+    items = sched.schedule()
+    assert items[0].positions[0] == 0 and len(items[0].tokens) == 14 and a.num_cached_tokens == 0
+    sched.update(items, [7])
+    assert a.num_registered_blocks == 3
+    assert [sched.allocator.block_to_hash[b] for b in a.block_table[:3]] == a.block_hashes
+    # a second request with the same 12-token prefix adopts those three blocks
+    b = Request("b", shared + [60, 61, 62], 4)
+    sched.add_request(b)
+    items = sched.schedule()
+    by_id = {it.request.request_id: it for it in items}
+    assert b.block_table[:3] == a.block_table[:3] and b.num_cached_tokens == 12
+    assert by_id["b"].tokens == [60, 61, 62] and by_id["b"].positions == [12, 13, 14] and by_id["b"].is_prefill
+    assert by_id["b"].slot_mapping == [b.block_table[3] * 4 + i for i in range(3)]
+    assert all(sched.allocator.ref_count[blk] == 2 for blk in a.block_table[:3])
+    assert b.block_table[3] not in a.block_table                    # the tail is private
+    assert sched.prefix_stats == {'requests': 2, 'prompt_tokens': 29, 'cached_tokens': 12}
+    # finishing one owner keeps the blocks alive for the other
+    sched.update(items, [0 if it.request is a else 9 for it in items])       # a hits EOS
+    assert a.is_finished and all(sched.allocator.ref_count[blk] == 1 for blk in b.block_table[:3])
+
+
+def test_fully_cached_prompt_still_computes_its_last_block():
+    sched = _prefix_sched()
+    prompt = list(range(1, 9))                                      # exactly 2 full blocks
+    first = Request("a", list(prompt), 1)
+    sched.add_request(first)
+    sched.update(sched.schedule(), [5])
+    assert first.is_finished and sched.allocator.num_free == 32     # blocks are free but keep their hashes
+    again = Request("b", list(prompt), 1)
+    sched.add_request(again)
+    items = sched.schedule()
+    assert again.num_cached_tokens == 4 and items[0].positions == [4, 5, 6, 7]
+    assert again.block_table[0] == first.block_table[0]             # revived from the free list
+    assert sched.allocator.ref_count[again.block_table[0]] == 1
+    assert again.block_table[0] not in sched.allocator.free_blocks
+
+
+def test_evicted_blocks_stop_matching():
+    sched = _prefix_sched(num_blocks=4)
+    a = Request("a", list(range(1, 9)) + [9], 1)                    # 3 blocks
+    sched.add_request(a)
+    sched.update(sched.schedule(), [5])
+    assert a.is_finished and len(sched.allocator.hash_to_block) == 2
+    filler = Request("f", list(range(100, 116)), 1)                 # needs all 4 blocks -> evicts both cached ones
+    sched.add_request(filler)
+    sched.update(sched.schedule(), [5])
+    assert not any(h in sched.allocator.hash_to_block for h in a.block_hashes)
+    b = Request("b", list(range(1, 9)) + [9], 1)
+    sched.add_request(b)
+    items = sched.schedule()
+    assert b.num_cached_tokens == 0 and items[0].positions[0] == 0
+
+
+def test_prefix_caching_off_changes_nothing():
+    """The default scheduler never touches the hash map (as in the reference)."""
+    from mini_vllm import BlockAllocator, Scheduler
+    sched = Scheduler(4, 64, 4, BlockAllocator(16, 4))
+    for name in ("a", "b"):
+        sched.add_request(Request(name, list(range(1, 10)), 2))
+    for _ in range(3):
+        items = sched.schedule()
+        sched.update(items, [3] * len(items))
+    assert not sched.allocator.hash_to_block and sched.prefix_stats['requests'] == 0
+
+
+def test_chunked_prefill_registers_blocks_as_chunks_complete():
+    sched = _prefix_sched(budget=6)
+    a = Request("a", list(range(1, 15)), 2)                         # 14 tokens: chunks of 6, 6, 2
+    sched.add_request(a)
+    seen = []
+    while a.is_prefill:
+        items = sched.schedule()
+        sched.update(items, [4])
+        seen.append((a.num_computed_tokens, a.num_registered_blocks))
+    assert seen == [(6, 1), (12, 3), (14, 3)]

@@ -112,6 +112,10 @@ class Request:
     block_table: List[int] = field(default_factory=list)
     is_finished: bool = False
     arrival_time: float = field(default_factory=time.time)
+    # prefix caching (only used when the scheduler enables it)
+    block_hashes: List[int] = field(default_factory=list)   # chained hash of every full prompt block
+    num_cached_tokens: int = 0                                # prompt tokens served from cached blocks
+    num_registered_blocks: int = 0                            # prompt blocks already offered to the cache
 
     @property
     def prompt_len(self) -> int:
@@ -141,6 +145,18 @@ class ScheduledRequest:
     slot_mapping: List[int]
 
 
+def prompt_block_hashes(token_ids: Sequence[int], block_size: int) -> List[int]:
+    """One hash per FULL block of the prompt, each chained to the hash of the block before it,
+    so equal hashes mean equal prefixes up to and including that block
+    (06_global_prefix_cache/global_kv_pool.py:471-500: hash((parent, tokens, extra)), seed 0)."""
+    hashes: List[int] = []
+    parent = 0
+    for start in range(0, len(token_ids) - block_size + 1, block_size):
+        parent = hash((parent, tuple(token_ids[start:start + block_size]), None))
+        hashes.append(parent)
+    return hashes
+
+
 class Scheduler:
     """First-come-first-served continuous batching with optional chunked prefill
     (05_mini_vllm/mini_vllm.py:164-337).
@@ -152,10 +168,20 @@ class Scheduler:
     purpose: a request admitted from the waiting queue with chunking disabled is
     scheduled whole even when it exceeds the remaining budget, and blocks obtained
     by a partially successful reservation stay with the request.
+
+    enable_prefix_caching (off by default; the reference's allocator carries the hash -> block
+    map, 05_mini_vllm/mini_vllm.py:62-104, but its scheduler never consults it): a request leaving
+    the waiting queue first adopts, through allocate(block_hash), the cached blocks matching the
+    longest prefix of its full prompt blocks and starts computing after them; every prompt block
+    is offered to the cache (mark_cached) once its K/V rows have been written.  At least one
+    prompt token is always computed, so a fully cached prompt re-computes its last block.
     """
 
     def __init__(self, max_num_seqs: int, max_num_batched_tokens: int, block_size: int,
-                 allocator: BlockAllocator, enable_chunked_prefill: bool = True):
+                 allocator: BlockAllocator, enable_chunked_prefill: bool = True,
+                 enable_prefix_caching: bool = False):
+        self.enable_prefix_caching = enable_prefix_caching
+        self.prefix_stats = {'requests': 0, 'prompt_tokens': 0, 'cached_tokens': 0}
         self.max_num_seqs = max_num_seqs
         self.max_num_batched_tokens = max_num_batched_tokens
         self.block_size = block_size
@@ -177,6 +203,29 @@ class Scheduler:
                 return False
             req.block_table.append(got)
         return True
+
+    def _adopt_cached_prefix(self, req: Request):
+        """Point the head of req.block_table at cached blocks holding the same prompt prefix."""
+        bs = self.block_size
+        req.block_hashes = prompt_block_hashes(req.prompt_token_ids, bs)
+        usable = min(len(req.block_hashes), (req.prompt_len - 1) // bs)   # leave >= 1 token to compute
+        for block_hash in req.block_hashes[:usable]:
+            if block_hash not in self.allocator.hash_to_block:
+                break
+            req.block_table.append(self.allocator.allocate(block_hash))
+        hit = len(req.block_table)
+        req.num_computed_tokens = req.num_cached_tokens = hit * bs
+        req.num_registered_blocks = hit
+        self.prefix_stats['requests'] += 1
+        self.prefix_stats['prompt_tokens'] += req.prompt_len
+        self.prefix_stats['cached_tokens'] += hit * bs
+
+    def _register_prompt_blocks(self, req: Request):
+        """Offer every prompt block whose rows are now all in the cache to the prefix map."""
+        full = min(req.num_computed_tokens, req.prompt_len) // self.block_size
+        for i in range(req.num_registered_blocks, min(full, len(req.block_hashes))):
+            self.allocator.mark_cached(req.block_table[i], req.block_hashes[i])
+        req.num_registered_blocks = max(req.num_registered_blocks, full)
 
     def _compute_slot_mapping(self, req: Request, tokens: Sequence[int], start_pos: int) -> List[int]:
         bs = self.block_size
@@ -225,9 +274,13 @@ class Scheduler:
         for req in self.waiting:
             admitted = False
             if room():
-                want = min(req.prompt_len, budget) if chunked else req.prompt_len
+                if self.enable_prefix_caching and not req.block_table and req.num_computed_tokens == 0:
+                    self._adopt_cached_prefix(req)
+                first = req.num_computed_tokens           # 0 unless a cached prefix was adopted
+                left = req.prompt_len - first
+                want = min(left, budget) if chunked else left
                 if want > 0 and self._ensure_blocks(req, want):
-                    batch.append(self._emit(req, req.prompt_token_ids[:want], 0, True))
+                    batch.append(self._emit(req, req.prompt_token_ids[first:first + want], first, True))
                     budget -= want
                     self.running.append(req)
                     admitted = True
@@ -243,6 +296,8 @@ class Scheduler:
         for item, token in zip(scheduled, next_token_ids):
             req = item.request
             req.num_computed_tokens += len(item.tokens)
+            if self.enable_prefix_caching and item.is_prefill:
+                self._register_prompt_blocks(req)
             if item.is_prefill and req.is_prefill:
                 continue                              # more prompt chunks to come
             req.output_token_ids.append(token)
@@ -804,14 +859,16 @@ class Sampler:
 class MiniVLLM:
     """schedule -> flatten -> model forward -> sample -> update
     (05_mini_vllm/mini_vllm.py:641-783).  Extra keyword arguments, all optional:
-    reference_compat (see module docstring) and dtype (parameter / KV cache dtype)."""
+    reference_compat (see module docstring), dtype (parameter / KV cache dtype), decode_graphs
+    (replay pure-decode steps as captured HIP graphs) and enable_prefix_caching (reuse the KV
+    blocks of equal prompt prefixes; needs true-context attention, so not with reference_compat)."""
 
     def __init__(self, vocab_size: int = 1000, hidden_size: int = 128, num_layers: int = 2,
                  num_heads: int = 4, intermediate_size: int = 512, num_kv_blocks: int = 256,
                  block_size: int = 16, max_num_seqs: int = 8, max_num_batched_tokens: int = 1024,
                  enable_chunked_prefill: bool = True, device: str = 'cpu',
                  reference_compat: bool = False, dtype: Optional[torch.dtype] = None,
-                 decode_graphs: bool = True):
+                 decode_graphs: bool = True, enable_prefix_caching: bool = False):
         self.device = torch.device(device)
         self.reference_compat = reference_compat
         # replay pure-decode steps as HIP graphs (device-resident engines only)
@@ -821,7 +878,8 @@ class MiniVLLM:
         self.scheduler = Scheduler(max_num_seqs=max_num_seqs,
                                    max_num_batched_tokens=max_num_batched_tokens,
                                    block_size=block_size, allocator=self.allocator,
-                                   enable_chunked_prefill=enable_chunked_prefill)
+                                   enable_chunked_prefill=enable_chunked_prefill,
+                                   enable_prefix_caching=enable_prefix_caching and not reference_compat)
         self.model = MiniTransformer(vocab_size=vocab_size, hidden_size=hidden_size,
                                      num_layers=num_layers, num_heads=num_heads,
                                      intermediate_size=intermediate_size,
