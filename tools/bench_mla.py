@@ -22,10 +22,12 @@ cos, sin = torch.cat([ang, ang], -1).cos(), torch.cat([ang, ang], -1).sin()
 ctx = torch.full((B,), S, dtype=torch.int32, device=dev)
 nbytes = B * S * (R + P) * 2 + B * H * (R + P) * 2 + B * H * R * 4
 flops = 2.0 * B * H * S * (R + P + R)
-for tgt in (None, 1024, 4096):
+for tgt in [int(x) for x in os.environ.get('MLA_TARGETS', '0,1024,2048,0').split(',')]:
     if tgt:
         os.environ['MI355_MLA_TARGET_WGS'] = str(tgt)
-    n = 30
+    else:
+        os.environ.pop('MI355_MLA_TARGET_WGS', None)
+    n = 60
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
     for i in range(n + 5):
         c, k = pools[i % sets]

@@ -22,6 +22,8 @@
 //   CU, ~18 KiB of loads each), not by software pipelining.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace mi355 {
@@ -226,21 +228,30 @@ __global__ void __launch_bounds__(kWave) mla_decode_kernel(const MlaParams p) {
 }
 
 // Four-wave variant for kv_lora_rank >= 128.  The workgroup shares 32-token tiles through a
-// double-buffered LDS image (the next tile's global loads are issued into registers before the
-// current tile is reduced); every wave computes the full 32 x 16 score tile (cheap next to the
-// memory time) but owns only a quarter of the latent output dims, which keeps the accumulators
-// at R/4 per wave and lets 2 workgroups (8 waves) share a CU.
+// double-buffered LDS image fed from two register stages (the global loads of the next TWO
+// tiles are in flight while the current one is reduced).  The score product is split four
+// ways: a wave multiplies one half of the R + P key dims for one 16-token half of the tile,
+// and the two partial 16 x 16 tiles of each half are summed through LDS, so a wave keeps half
+// of the query fragments in registers and reads a quarter of the tile; each wave then owns a
+// quarter of the latent output dims for all 32 tokens.  Registers and LDS stay low enough for
+// 2 workgroups (8 waves) per CU.
 template <class Tag, int R, int PP>
 __global__ void __launch_bounds__(256, 2) mla_decode_kernel_w4(const MlaParams p) {
   constexpr int DK = R + PP;
   constexpr int KS = DK / 32;
+  constexpr int KSW = (KS + 1) / 2;       // k-steps of the score product per wave
   constexpr int OTW = R / 64;             // 16-dim output tiles per wave
   constexpr int CPR = DK / 8;
   constexpr int ROWB = DK * 2 + 16;
-  constexpr int NCH = kTok2 * CPR;
-  constexpr int NLOAD = (NCH + 255) / 256;
-  constexpr int MAXPAIR = 4;              // rope pairs per thread (P <= 64 -> half <= 32 -> 32 / 8 groups)
+  constexpr int CCH = R / 8;              // 16-byte chunks of the c_kv part of a row
+  constexpr int RSTEP = 256 / CCH;        // rows covered by one pass of the 256 threads over c_kv chunks
+  constexpr int NCKV = kTok2 / RSTEP;     // c_kv loads per thread per tile
+  constexpr int RCH = PP / 8;             // chunks of the (padded) k_rope part of a row
+  constexpr int NLOAD = NCKV + 1;         // + one k_rope chunk per thread
+  constexpr int MAXPAIR = 4;              // rope pairs per thread: 4 consecutive dims (P <= 64 -> half <= 32 = 8 x 4)
+  static_assert(kTok2 * RCH <= 256 && CPR == CCH + RCH, "tile staging layout");
   __shared__ __attribute__((aligned(16))) unsigned char tiles[2][kTok2 * ROWB];
+  __shared__ f32x4 part[4][kWave];        // per-wave partial scores of the current tile
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
   int bid = blockIdx.x;
@@ -256,14 +267,17 @@ __global__ void __launch_bounds__(256, 2) mla_decode_kernel_w4(const MlaParams p
   const int head = ht * kHeadTile + c;
   const bool head_ok = head < p.H;
 
-  u32x4 qf[KS];
+  // Query fragments of this wave's slice [ks0, ks1) of the key dims; it scores tile rows 16*su .. +16.
+  const int su = wave >> 1;
+  const int ks0 = ((wave & 1) * KS) / 2, ks1 = (((wave & 1) + 1) * KS) / 2;
+  u32x4 qf[KSW];
   {
     const char* qrow = static_cast<const char*>(p.q) + ((int64_t)row * p.q_stride_row + (int64_t)head * (R + p.P)) * 2;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int d = 32 * ks + 8 * g;
-      const bool ok = head_ok && (d < R || d - R < p.P);
-      qf[ks] = ok ? *reinterpret_cast<const u32x4*>(qrow + d * 2) : u32x4{0u, 0u, 0u, 0u};
+    for (int i = 0; i < KSW; ++i) {
+      const int d = 32 * (ks0 + i) + 8 * g;
+      const bool ok = head_ok && ks0 + i < ks1 && (d < R || d - R < p.P);
+      qf[i] = ok ? *reinterpret_cast<const u32x4*>(qrow + d * 2) : u32x4{0u, 0u, 0u, 0u};
     }
   }
   f32x4 o[OTW];
@@ -274,72 +288,104 @@ __global__ void __launch_bounds__(256, 2) mla_decode_kernel_w4(const MlaParams p
   const char* ckv = static_cast<const char*>(p.ckv) + (int64_t)seq * p.ckv_stride_seq * 2;
   const char* krope = static_cast<const char*>(p.krope) + (int64_t)seq * p.krope_stride_seq * 2;
   const int half = p.P >> 1;
-  const int rtok = tid & 31, rgrp = tid >> 5;     // rope rotation: token of the tile, pair group 0..7
+  // rope rotation: thread = (token of the tile, group of 4 consecutive pairs), so that the 8 lanes
+  // of a token read one contiguous 128-byte run of the cos / sin row
+  const int rtok = tid >> 3, rgrp = tid & 7;
+  const bool r_live = 4 * rgrp < half;
   const int cstride = (int)p.ckv_stride_tok, rstride = (int)p.krope_stride_tok;   // host checks S * stride < 2^30
 
-  u32x4 stage[NLOAD];
+  // Staging layout: thread -> one fixed c_kv column chunk for rows crow, crow + RSTEP, ... and
+  // one k_rope chunk (row krow, chunk kcol), so the per-load state is one row index.
+  const int ccol = tid % CCH, crow = tid / CCH;
+  const int kcol = tid % RCH, krow = tid / RCH;
+  const bool k_live = kcol * 8 < p.P;
+  const int kcol_ld = k_live ? kcol : 0;
+  u32x4 stage_a[NLOAD], stage_b[NLOAD];
   float rc[MAXPAIR], rs[MAXPAIR];
-  auto issue_loads = [&](int t0) {
+  auto issue_loads = [&](int t0, u32x4 (&stage)[NLOAD]) {
 #pragma unroll
-    for (int i = 0; i < NLOAD; ++i) {
-      const int ch = tid + 256 * i;
-      const int tt = ch / CPR, dc = ch - tt * CPR;
-      const int tok = min(t0 + tt, t_end - 1);
-      const int d = dc * 8;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (ch < NCH) {
-        // 32-bit byte offsets from the (wave-uniform) sequence base keep the per-load address state small
-        if (d < R) v = load16<true>(ckv + (uint32_t)((tok * cstride + d) * 2));
-        else if (d - R < p.P) v = load16<true>(krope + (uint32_t)((tok * rstride + (d - R)) * 2));
-      }
-      stage[i] = v;
+    for (int i = 0; i < NCKV; ++i) {
+      const int tok = min(t0 + crow + RSTEP * i, t_end - 1);   // rows past the end re-read the last one (masked later)
+      // 32-bit byte offsets from the (wave-uniform) sequence base keep the per-load address state small
+      stage[i] = load16<true>(ckv + (uint32_t)((tok * cstride + ccol * 8) * 2));
     }
+    // unconditional (address clamped into the row) so the compiler can count outstanding loads
+    // exactly; lanes beyond the rope width are zeroed when the stage is written to LDS
+    const int tok = min(t0 + min(krow, kTok2 - 1), t_end - 1);
+    stage[NCKV] = load16<true>(krope + (uint32_t)((tok * rstride + kcol_ld * 8) * 2));
+  };
+  // cos / sin of the rope pairs this thread rotates in tile t0.  Issued BEFORE the data loads
+  // of the tile after it, so waiting for them never waits for those.
+  auto issue_rope_factors = [&](int t0) {
     const int pos = min(min(t0 + rtok, t_end - 1), p.table_len - 1);
+    const int col = r_live ? 4 * rgrp : 0;   // unconditional loads; groups beyond the rope width are never rotated
+    const f32x4 cv = *reinterpret_cast<const f32x4*>(p.cos_t + (int64_t)pos * p.P + col);
+    const f32x4 sv = *reinterpret_cast<const f32x4*>(p.sin_t + (int64_t)pos * p.P + col);
 #pragma unroll
     for (int k = 0; k < MAXPAIR; ++k) {
-      const int i = rgrp + 8 * k;
-      rc[k] = i < half ? p.cos_t[(int64_t)pos * p.P + i] : 1.f;
-      rs[k] = i < half ? p.sin_t[(int64_t)pos * p.P + i] : 0.f;
+      rc[k] = cv[k];
+      rs[k] = sv[k];
     }
   };
 
   const int ntiles = t_end > t_begin ? (t_end - t_begin + kTok2 - 1) / kTok2 : 0;
-  if (ntiles > 0) issue_loads(t_begin);
-  for (int t = 0; t < ntiles; ++t) {
+
+  // One tile: registers -> LDS, rotate the rope part, refill the same registers with the tile
+  // two steps ahead, then scores / softmax / weighted sum from LDS.
+  auto process = [&](int t, u32x4 (&stage)[NLOAD], auto steady) {
     const int t0 = t_begin + t * kTok2;
     unsigned char* tile = tiles[t & 1];
 #pragma unroll
-    for (int i = 0; i < NLOAD; ++i) {
-      const int ch = tid + 256 * i;
-      const int tt = ch / CPR, dc = ch - tt * CPR;
-      if (ch < NCH) *reinterpret_cast<u32x4*>(tile + tt * ROWB + dc * 16) = stage[i];
-    }
+    for (int i = 0; i < NCKV; ++i)
+      *reinterpret_cast<u32x4*>(tile + (crow + RSTEP * i) * ROWB + ccol * 16) = stage[i];
+    if (krow < kTok2)
+      *reinterpret_cast<u32x4*>(tile + krow * ROWB + R * 2 + kcol * 16) = k_live ? stage[NCKV] : u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
-    {   // rotate the rope part of the 32 rows in place (256 threads: token x 8 pair groups)
-      typename Tag::elem_t* kr = reinterpret_cast<typename Tag::elem_t*>(tile + rtok * ROWB + R * 2);
+    if (r_live) {   // rotate the rope part of the 32 rows in place: 4 (lo, hi) pairs per thread, 8-byte accesses
+      unsigned char* kr = tile + rtok * ROWB + R * 2 + rgrp * 8;
+      const u32x2 lo2 = *reinterpret_cast<const u32x2*>(kr), hi2 = *reinterpret_cast<const u32x2*>(kr + half * 2);
+      float lo[4], hi[4], nlo[4], nhi[4];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        lo[2 * k] = Tag::to_float((typename Tag::elem_t)(lo2[k] & 0xffffu));
+        lo[2 * k + 1] = Tag::to_float((typename Tag::elem_t)(lo2[k] >> 16));
+        hi[2 * k] = Tag::to_float((typename Tag::elem_t)(hi2[k] & 0xffffu));
+        hi[2 * k + 1] = Tag::to_float((typename Tag::elem_t)(hi2[k] >> 16));
+      }
 #pragma unroll
       for (int k = 0; k < MAXPAIR; ++k) {
-        const int i = rgrp + 8 * k;
-        if (i < half) {
-          const float lo = Tag::to_float(kr[i]), hi = Tag::to_float(kr[i + half]);
-          kr[i] = Mma16<Tag>::from_f(lo * rc[k] - hi * rs[k]);
-          kr[i + half] = Mma16<Tag>::from_f(hi * rc[k] + lo * rs[k]);
-        }
+        nlo[k] = lo[k] * rc[k] - hi[k] * rs[k];
+        nhi[k] = hi[k] * rc[k] + lo[k] * rs[k];
       }
+      *reinterpret_cast<u32x2*>(kr) = u32x2{Mma16<Tag>::pack2(nlo[0], nlo[1]), Mma16<Tag>::pack2(nlo[2], nlo[3])};
+      *reinterpret_cast<u32x2*>(kr + half * 2) = u32x2{Mma16<Tag>::pack2(nhi[0], nhi[1]), Mma16<Tag>::pack2(nhi[2], nhi[3])};
     }
     __syncthreads();
-    if (t + 1 < ntiles) issue_loads(t0 + kTok2);
+    if constexpr (decltype(steady)::value) {   // main loop: both refills exist, no branches around the loads
+      issue_rope_factors(t0 + kTok2);
+      issue_loads(t0 + 2 * kTok2, stage);
+    } else {
+      if (t + 1 < ntiles) issue_rope_factors(t0 + kTok2);
+      if (t + 2 < ntiles) issue_loads(t0 + 2 * kTok2, stage);
+    }
 
+    // partial S^T (16 tokens x 16 heads over half of the key dims), exchanged through LDS
+    {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < KSW; ++i) {
+        // a step past this wave's slice (odd KS) multiplies by a zero query fragment
+        const int ks = min(ks0 + i, KS - 1);
+        const u32x4 a = *reinterpret_cast<const u32x4*>(tile + (16 * su + c) * ROWB + (32 * ks + 8 * g) * 2);
+        acc = Mma16<Tag>::run(a, qf[i], acc);
+      }
+      part[wave][lane] = acc;
+    }
+    __syncthreads();
     f32x4 st[2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      st[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const u32x4 a = *reinterpret_cast<const u32x4*>(tile + (16 * u + c) * ROWB + (32 * ks + 8 * g) * 2);
-        st[u] = Mma16<Tag>::run(a, qf[ks], st[u]);
-      }
-    }
+    for (int u = 0; u < 2; ++u) st[u] = part[2 * u][lane] + part[2 * u + 1][lane];
+
     float s[8], mx = -__builtin_inff();
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -382,6 +428,28 @@ __global__ void __launch_bounds__(256, 2) mla_decode_kernel_w4(const MlaParams p
       const u32x4 va = {lo2[0], lo2[1], hi2[0], hi2[1]};
       o[i] = Mma16<Tag>::run(va, pb, o[i]);
     }
+  };
+
+  // Issue order in the steady state is data(t+2), factors(t+3), data(t+3), ...; the prologue
+  // follows the same order so the compiler's outstanding-load counts agree on both loop edges.
+  int t = 0;
+  if (ntiles >= 4) {
+    issue_loads(t_begin, stage_a);
+    issue_rope_factors(t_begin);
+    issue_loads(t_begin + kTok2, stage_b);
+    do {
+      process(t, stage_a, std::true_type{});
+      process(t + 1, stage_b, std::true_type{});
+      t += 2;
+    } while (t + 3 < ntiles);
+  } else if (ntiles > 0) {
+    issue_loads(t_begin, stage_a);
+    issue_rope_factors(t_begin);
+    if (ntiles > 1) issue_loads(t_begin + kTok2, stage_b);
+  }
+  for (; t < ntiles; t += 2) {   // last one to three tiles
+    process(t, stage_a, std::false_type{});
+    if (t + 1 < ntiles) process(t + 1, stage_b, std::false_type{});
   }
 
   if (!head_ok) return;
@@ -450,10 +518,12 @@ int mla_plan(int rows, int H, int R, int P, int max_context, int dtype, MlaPlan*
   pl.n_ht = (H + kHeadTile - 1) / kHeadTile;
   const int ctx = max_context > 0 ? max_context : 1;
   const int64_t base = (int64_t)rows * pl.n_ht;
-  // one-wave kernel (R < 128): 8 workgroups per CU; four-wave kernel: 2 per CU
-  const int target = env_int2("MI355_MLA_TARGET_WGS", R >= 128 ? 512 : 2048);
+  // one-wave kernel (R < 128): 8 workgroups per CU.  Four-wave kernel: one workgroup per CU
+  // before tokens are split -- with two tiles of prefetch per workgroup, few long workgroups
+  // beat many short ones (measured at 256 rows x 4096 tokens: 187 us unsplit, 193 us with 2
+  // splits, 212 us with 4).
+  const int target = env_int2("MI355_MLA_TARGET_WGS", R >= 128 ? 256 : 2048);
   int64_t want = ceil_div64(target, base);
-  if (R >= 128 && want < 4) want = 4;                           // measured: 4 splits beat 2 at 256 rows x 4096 tokens
   const int64_t most = ctx / 128 > 0 ? ctx / 128 : 1;           // at least 4 steps per workgroup
   if (want > most) want = most;
   if (want < 1) want = 1;
@@ -523,7 +593,8 @@ extern "C" int mi355_mla_decode(float* out, const void* q, int64_t q_stride_row,
   if (q_stride_row % 8 || ckv_stride_tok % 8 || ckv_stride_seq % 8 || krope_stride_tok % 8 || krope_stride_seq % 8 ||
       q_stride_row < (int64_t)H * (R + P) || ckv_stride_tok < R || krope_stride_tok < P)
     return fail(MI355_EINVAL, "mla_decode: strides must keep rows 16-byte aligned");
-  if (((uintptr_t)out | (uintptr_t)q | (uintptr_t)c_kv | (uintptr_t)k_rope) & 15)
+  if (((uintptr_t)out | (uintptr_t)q | (uintptr_t)c_kv | (uintptr_t)k_rope | (uintptr_t)cos_table |
+       (uintptr_t)sin_table) & 15)
     return fail(MI355_EINVAL, "mla_decode: tensors must be 16-byte aligned");
   if ((int64_t)max_context * ckv_stride_tok >= (1LL << 30) || (int64_t)max_context * krope_stride_tok >= (1LL << 30))
     return fail(MI355_EUNSUPPORTED, "mla_decode: one sequence's cache must span < 2^30 elements");

@@ -339,18 +339,31 @@ int make_plan(int B, int Hq, int Hkv, int D, int block_size, int max_context, in
   if (max_context < 0) return fail(MI355_EINVAL, "max_context %d", max_context);
   DecodePlan pl;
   pl.nw = 8;
-  pl.hpw = (Hkv % 8 == 0) ? 8 : (Hkv % 4 == 0) ? 4 : (Hkv % 2 == 0) ? 2 : 1;
-  pl.sub = pl.nw / pl.hpw;
-  pl.hgroups = Hkv / pl.hpw;
   const int gq = Hq / Hkv;
   pl.G = gq >= 8 ? 8 : gq > 2 ? 4 : gq;  // 1, 2, 4 or 8 query heads per wave
   pl.qchunks = (gq + pl.G - 1) / pl.G;
   const int lpt = D / elems_per_lane(dtype);
   const int ts = (kWave / lpt) * steps_for_group(pl.G);
-  const int quantum = pl.sub * ts;  // tokens one workgroup consumes per pipeline step
   const int ctx = max_context > 0 ? max_context : 1;
-  const int64_t base_wgs = (int64_t)B * pl.hgroups * pl.qchunks;
   const int target = env_int("MI355_PAGED_TARGET_WGS", 256);  // one workgroup per CU before splitting tokens
+  // Heads per workgroup.  Eight kv heads per workgroup fetch the eight head tiles of a block
+  // (contiguous in the [block][head][row][d] layout) together.  When that leaves CUs idle,
+  // fewer heads per workgroup with the freed waves taking token sub-ranges of the same head
+  // fills the chip without a second launch: sub-ranges merge through LDS inside the
+  // workgroup, token splits across workgroups need the merge kernel and a workspace trip.
+  pl.hpw = (Hkv % 8 == 0) ? 8 : (Hkv % 4 == 0) ? 4 : (Hkv % 2 == 0) ? 2 : 1;
+  const int forced_hpw = env_int("MI355_PAGED_HPW", 0);
+  if (forced_hpw > 0 && forced_hpw <= pl.hpw && pl.hpw % forced_hpw == 0) {
+    pl.hpw = forced_hpw;
+  } else if (!causal) {
+    while (pl.hpw > 1 && (int64_t)B * (Hkv / pl.hpw) * pl.qchunks < target &&
+           ctx >= 2 * ts * (pl.nw / pl.hpw) * 2)  // every sub-range keeps >= 2 pipeline steps
+      pl.hpw /= 2;
+  }
+  pl.sub = pl.nw / pl.hpw;
+  pl.hgroups = Hkv / pl.hpw;
+  const int quantum = pl.sub * ts;  // tokens one workgroup consumes per pipeline step
+  const int64_t base_wgs = (int64_t)B * pl.hgroups * pl.qchunks;
   int64_t want = ceil_div64(target, base_wgs);
   const int64_t most = ctx / (2 * quantum) > 0 ? ctx / (2 * quantum) : 1;  // >= 2 steps per wave
   if (want > most) want = most;
