@@ -526,8 +526,9 @@ extern "C" int mi355_prefill_causal(void* out, const void* q, const void* k, con
     return fail(MI355_EINVAL, "prefill_causal: tensors must be 16-byte aligned");
   // 16-bit inputs at head_dim 64/128 go to the matrix-core kernel; everything else (fp32,
   // other head dims) runs the VALU decode kernel in causal mode below.
-  // MI355_PREFILL_VALU=1 forces the latter (A/B measurements).
-  if (prefill_mfma_supported(dtype, D) && !env_int("MI355_PREFILL_VALU", 0))
+  // MI355_PREFILL_VALU=1 forces the latter (A/B measurements).  The matrix-core kernel takes
+  // the row maximum before scaling, which needs a positive scale.
+  if (prefill_mfma_supported(dtype, D) && scale > 0.f && !env_int("MI355_PREFILL_VALU", 0))
     return prefill_mfma_launch(out, q, k, v, q_stride_tok, kv_stride_tok, cu_seqlens, nseq, total_tokens,
                                max_seqlen, Hq, Hkv, D, scale, dtype, static_cast<hipStream_t>(stream));
   DecodeParams p;

@@ -55,7 +55,9 @@ struct Mma<BF16> {
                                                    c, 0, 0, 0);
   }
   static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-    return BF16::round1(lo) | (BF16::round1(hi) << 16);
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));   // one v_cvt_pk_bf16_f32
   }
 };
 template <>
@@ -72,15 +74,18 @@ struct Mma<F16> {
   }
 };
 
+// Two workgroups (8 waves) per CU: with a 256-register budget the 64 accumulator registers of a
+// wave stay in VGPRs, where the softmax arithmetic reads and writes them directly (a tighter
+// budget parks them in AccVGPRs and pays a copy per register per use).
 template <class Tag, int D>
-__global__ void __launch_bounds__(kWaves * kWave) prefill_mfma_kernel(const PrefillParams p) {
+__global__ void __launch_bounds__(kWaves * kWave, 2) prefill_mfma_kernel(const PrefillParams p) {
   constexpr int KS = D / 16;          // k-steps of the S^T product (over head_dim)
   constexpr int DT = D / 32;          // 32-row tiles of O^T (over head_dim)
   constexpr int ROWB = D * 2;         // bytes per K / V row in LDS
   constexpr int CPR = D / 8;          // 16-byte chunks per row
   constexpr int LOADS = kKT * CPR / (kWaves * kWave);  // 16-byte chunks per thread per tile (K, and again V)
-  __shared__ __attribute__((aligned(16))) unsigned char sK[kKT * ROWB];
-  __shared__ __attribute__((aligned(16))) unsigned char sV[kKT * ROWB];
+  __shared__ __attribute__((aligned(16))) unsigned char sK2[2][kKT * ROWB];   // double-buffered tiles:
+  __shared__ __attribute__((aligned(16))) unsigned char sV2[2][kKT * ROWB];   // one barrier per tile
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 31, h = lane >> 5;
@@ -130,7 +135,9 @@ __global__ void __launch_bounds__(kWaves * kWave) prefill_mfma_kernel(const Pref
       vreg[i] = *reinterpret_cast<const u32x4*>(vbase + off);
     }
   };
-  auto write_lds = [&]() {
+  auto write_lds = [&](int buf) {
+    unsigned char* sK = sK2[buf];
+    unsigned char* sV = sV2[buf];
 #pragma unroll
     for (int i = 0; i < LOADS; ++i) {
       const int ch = tid + i * (kWaves * kWave);
@@ -140,63 +147,66 @@ __global__ void __launch_bounds__(kWaves * kWave) prefill_mfma_kernel(const Pref
     }
   };
 
+  // Tile t is reduced from buffer t&1 while tile t+1 sits in registers; at the end of the step
+  // those registers go to the other buffer (last read in step t-1, which every wave has left)
+  // and the loads of tile t+2 are issued.
   issue_loads(0);
+  write_lds(0);
+  if (ntiles > 1) issue_loads(1);
+  __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
-    __syncthreads();                 // every wave is done reading the previous tile
-    write_lds();
-    __syncthreads();
-    if (t + 1 < ntiles) issue_loads(t + 1);
-
+    const unsigned char* sK = sK2[t & 1];
+    const unsigned char* sV = sV2[t & 1];
     const int kv0 = t * kKT;
-    if (kv0 > qw0 + kQW - 1) continue;   // tile entirely above this wave's diagonal (wave-uniform)
+    if (kv0 <= qw0 + kQW - 1) {          // else: tile entirely above this wave's diagonal (wave-uniform)
 
     // ---- S^T = K . Q^T for the two 32-key halves of the tile
     f32x16 st[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
       const int row = 32 * kt + c;
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         const u32x4 a = *reinterpret_cast<const u32x4*>(sK + row * ROWB + (((2 * s + h) ^ (row & 7)) << 4));
-        st[kt] = Mma<Tag>::run(a, qf[s], st[kt]);
+        st[kt] = Mma<Tag>::run(a, qf[s], s == 0 ? f32x16(0.f) : st[kt]);   // first step accumulates onto the constant 0
       }
     }
-    // ---- scale, causal mask, online softmax (the lane's query is column c)
+    // ---- causal mask, online softmax (the lane's query is column c).  The scale is positive, so
+    // the row maximum is taken on the raw scores and scale and shift fold into one fma per score.
     const bool diag = kv0 + kKT - 1 > qw0;           // some key of the tile may exceed some query of the wave
-    float mx = -__builtin_inff();
+    if (diag) {
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+      for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float s = st[kt][r] * p.scale_log2e;
-        if (diag) {
+        for (int r = 0; r < 16; ++r) {
           const int key = kv0 + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * h;
-          s = key <= my_q ? s : -__builtin_inff();
+          st[kt][r] = key <= my_q ? st[kt][r] : -__builtin_inff();
         }
-        st[kt][r] = s;
-        mx = fmaxf(mx, s);
-      }
+    }
+    float mx = fmaxf(st[0][0], st[1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = __builtin_fmaxf(__builtin_fmaxf(mx, st[0][r]), st[1][r]);   // v_max3_f32
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
+    const float m_new = fmaxf(m_run, mx * p.scale_log2e);
     const float f = fast_exp2(m_run - m_new);
     m_run = m_new;
+    f32x16 psum16;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      st[kt] = st[kt] * p.scale_log2e - m_new;       // packed fma
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[kt][r] = fast_exp2(st[kt][r]);
+    }
+    psum16 = st[0] + st[1];                          // packed adds
     float psum = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = fast_exp2(st[kt][r] - m_new);
-        st[kt][r] = e;
-        psum += e;
-      }
+    for (int r = 0; r < 16; ++r) psum += psum16[r];
     psum += __shfl_xor(psum, 32);
     l_run = l_run * f + psum;
+    if (!__all(f == 1.0f)) {                         // the running maximum moved for some query of the wave
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[dt][r] *= f;
+      for (int dt = 0; dt < DT; ++dt) o[dt] *= f;
+    }
 
     // ---- O^T += V^T . P^T : k-step s4 covers keys 16*s4 .. 16*s4+15 of the tile.
     // Fragment element j of lane half h is key 16*s4 + 8*(j>>2) + 4*h + (j&3): exactly
@@ -224,6 +234,12 @@ __global__ void __launch_bounds__(kWaves * kWave) prefill_mfma_kernel(const Pref
         o[dt] = Mma<Tag>::run(va, pb, o[dt]);
       }
     }
+    }
+    if (t + 1 < ntiles) {
+      write_lds((t + 1) & 1);
+      if (t + 2 < ntiles) issue_loads(t + 2);
+    }
+    __syncthreads();
   }
 
   // ---- normalise and store: lane (c,h) holds O[my_q][32*dt + 8*(r>>2) + 4*h + (r&3)]
