@@ -143,7 +143,8 @@ def main():
     from mi355_paged import dp, ops
     cfg = CONFIGS[args.config]
     B, S, H, D, BS = cfg['B'], cfg['S'], cfg['H'], cfg['D'], cfg['BS']
-    inp = build_inputs(cfg, device, seed=rank)
+    # small configs rotate through more pools so that a step never finds its KV in the 256 MiB Infinity Cache
+    inp = build_inputs(cfg, device, seed=rank, sets=2 if args.config == 'metric' else 4)
     nsets = len(inp['pools'])
     out = torch.empty((B, H, D), dtype=torch.bfloat16, device=device)
     ids = torch.empty((B,), dtype=torch.int32, device=device)
@@ -213,10 +214,14 @@ def main():
                          "p50_ms": round(kernel_ms[len(kernel_ms) // 2], 5),
                          "p90_ms": round(kernel_ms[(len(kernel_ms) * 9) // 10], 5)},
         }
-        traffic_file = os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')
-        if args.config == 'metric' and os.path.exists(traffic_file):
-            with open(traffic_file) as f:
+        # HBM bytes per launch from the committed counter passes (tools/collect_profiles.sh +
+        # tools/pmc_traffic.py; counters cannot be read inside this process); newest file wins
+        import glob
+        traffic_files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')))
+        if args.config == 'metric' and traffic_files:
+            with open(traffic_files[-1]) as f:
                 line["roofline"]["traffic"] = json.load(f).get("hbm_bytes_per_launch")
+            line["roofline"]["traffic_source"] = os.path.relpath(traffic_files[-1], ROOT)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, inp)
         print(json.dumps(line), flush=True)

@@ -1,0 +1,46 @@
+#!/bin/bash
+# Collect the measurements kept under profiles/: run on the GPU box from the repo root,
+#   tools/collect_profiles.sh <tag>      (writes gpurun_out/<tag>/...)
+# Kernel-trace passes and counter (--pmc) passes are separate rocprofv3 runs.
+set -e
+TAG=${1:-r1c}
+OUT=$PWD/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+step() { echo "== $*" >&2; }
+
+step bench.py
+timeout -k 10 300 python3 bench.py > "$OUT/bench_line.json" 2> "$OUT/bench.err"
+timeout -k 10 300 python3 bench.py --config c2 --no-cpu-baseline > "$OUT/bench_line_c2.json" 2>> "$OUT/bench.err"
+
+step kernel trace of bench.py
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_bench" -o bench -- \
+  python3 bench.py --steps 100 --no-cpu-baseline > "$OUT/bench_line_under_rocprof.json" 2> "$OUT/trace_bench.log"
+
+step kernel trace of the MLA and prefill benches
+MLA_TARGETS=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_mla" -o mla -- \
+  python3 tools/bench_mla.py 256 16 4096 > "$OUT/mla_under_rocprof.txt" 2> "$OUT/trace_mla.log"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_prefill" -o prefill -- \
+  python3 tools/bench_prefill.py 4 8192 8 8 64 > "$OUT/prefill_under_rocprof.txt" 2> "$OUT/trace_prefill.log"
+
+step counters: HBM traffic of the decode kernel, MFMA activity of the prefill kernel
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o fetch -- \
+  python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2> "$OUT/pmc_fetch.log"
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o write -- \
+  python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2> "$OUT/pmc_write.log"
+timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE \
+  --output-format csv -d "$OUT/pmc_prefill" -o prefill -- \
+  python3 tools/bench_prefill.py 4 8192 8 8 64 > /dev/null 2> "$OUT/pmc_prefill.log"
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_mla_fetch" -o fetch -- \
+  python3 tools/bench_mla.py 256 16 4096 > /dev/null 2> "$OUT/pmc_mla_fetch.log"
+
+step secondary benchmarks
+{
+  timeout -k 10 200 python3 tools/bench_misc.py
+  timeout -k 10 200 python3 tools/bench_gqa.py
+  for a in "64 16 4096" "256 16 4096" "128 16 8192"; do MLA_TARGETS=0,0 timeout -k 10 120 python3 tools/bench_mla.py $a | tail -1; done
+  for a in "16 2048 8 8 64" "4 8192 8 8 64" "8 4096 16 2 128"; do timeout -k 10 120 python3 tools/bench_prefill.py $a; done
+  timeout -k 10 200 python3 tools/bench_engine.py 256 512 32
+  timeout -k 10 200 python3 tools/bench_engine.py 128 256 64
+} > "$OUT/secondary.txt" 2> "$OUT/secondary.err"
+find "$OUT" -name '*.csv' | head -40 >&2
