@@ -122,6 +122,55 @@ def test_decode_shape_sweep(ops, device, shape, dtype):
     np.testing.assert_allclose(out, want, **(F32_TOL if dtype == torch.float32 else LOWP_TOL))
 
 
+@pytest.mark.parametrize('shape', [
+    # B, Hq, Hkv, D, BS, max_ctx -- grouped-query shapes served by the matrix-core decode kernel
+    (3, 32, 8, 128, 16, 300),      # 4 query heads per kv head, 4 kv heads per workgroup
+    (2, 64, 8, 128, 16, 1100),     # 8 per kv head
+    (4, 16, 2, 64, 16, 700),       # 2 kv heads: waves take token sub-ranges (LDS merge)
+    (5, 8, 1, 64, 16, 900),        # 1 kv head, 4 sub-ranges
+    (2, 16, 1, 64, 8, 5000),       # long context: token splits + merge kernel
+    (3, 20, 4, 64, 16, 200),       # 5 query heads per kv head (partial head tile)
+    (2, 40, 2, 128, 32, 333),      # 20 per kv head: two head tiles
+    (3, 24, 6, 64, 3, 150),        # block size that is not a power of two
+    (2, 16, 4, 64, 1, 70),         # one token per block
+    (130, 32, 4, 64, 16, 96),      # many short sequences
+])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('layout', ['NHSD', 'NSHD'])
+def test_decode_grouped_query_matrix_core(ops, device, shape, dtype, layout):
+    B, Hq, Hkv, D, BS, max_ctx = shape
+    rng = np.random.default_rng(hash(shape) % (2 ** 31))
+    q, cache, bt, ctx = _random_batch(rng, B, Hq, Hkv, D, BS, max_ctx)
+    ctx[0] = max_ctx
+    ctx[-1] = 1                                        # a single-token context
+    if B > 2:
+        ctx[1] = max(1, (max_ctx // 32) * 32)          # ends exactly on a pipeline-step boundary
+    q = torch.from_numpy(q).to(dtype).float().numpy()
+    cache = torch.from_numpy(cache).to(dtype).float().numpy()
+    want = orc.paged_decode_batch(q, cache[0], cache[1], bt, ctx, BS, dtype=np.float64)
+    out = _decode_on_gpu(ops, device, q, cache, bt, ctx, dtype, layout)
+    np.testing.assert_allclose(out, want, **LOWP_TOL)
+
+
+def test_decode_grouped_query_matches_valu_kernel(ops, device, monkeypatch):
+    """Same inputs through the matrix-core kernel and (MI355_DECODE_GQA_MFMA=0) the VALU kernel:
+    both within tolerance of the oracle and of each other; zero-length rows give zeros in both."""
+    rng = np.random.default_rng(77)
+    B, Hq, Hkv, D, BS, max_ctx = 6, 32, 4, 128, 16, 400
+    q, cache, bt, ctx = _random_batch(rng, B, Hq, Hkv, D, BS, max_ctx)
+    ctx[2] = 0
+    q = torch.from_numpy(q).to(torch.bfloat16).float().numpy()
+    cache = torch.from_numpy(cache).to(torch.bfloat16).float().numpy()
+    mfma = _decode_on_gpu(ops, device, q, cache, bt, ctx, torch.bfloat16)
+    monkeypatch.setenv('MI355_DECODE_GQA_MFMA', '0')
+    valu = _decode_on_gpu(ops, device, q, cache, bt, ctx, torch.bfloat16)
+    np.testing.assert_allclose(mfma, valu, **LOWP_TOL)
+    assert not mfma[2].any() and not valu[2].any()
+    keep = [i for i in range(B) if ctx[i] > 0]
+    want = orc.paged_decode_batch(q[keep], cache[0], cache[1], bt[keep], [ctx[i] for i in keep], BS, dtype=np.float64)
+    np.testing.assert_allclose(mfma[keep], want, **LOWP_TOL)
+
+
 def test_decode_ignores_unused_and_clamps_bad_block_ids(ops, device):
     """Entries of a block-table row past ceil(context/block_size) are never read, whatever they
     hold; ids outside the pool inside the used range are clamped (wrong answer for that row,

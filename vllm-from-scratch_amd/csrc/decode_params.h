@@ -1,0 +1,45 @@
+// Launch description shared by the paged-decode kernels (paged_decode.hip: VALU kernel, merge
+// kernel, planning; paged_decode_gqa.hip: matrix-core kernel for grouped-query shapes).
+#pragma once
+
+#include "common.h"
+
+namespace mi355 {
+
+constexpr int kMaxBtEntries = 8192;  // block-table entries one workgroup may stage in LDS
+constexpr float kNegBig = -1.0e30f;  // running-max start: finite so that exp2(m - m) never sees inf - inf
+
+struct DecodeParams {
+  void* out;
+  const void* q;
+  const void* kc;
+  const void* vc;
+  const int32_t* bt;
+  const int32_t* ctx;
+  const int32_t* cu;  // non-null selects causal mode over packed sequences (VALU kernel only)
+  int nseq;
+  float* ws_acc;  // [B, Hq, nsplit, D]
+  float* ws_ml;   // [B, Hq, nsplit, 2]  (max in log2 units, sum)
+  int64_t q_stride_seq, s_blk, s_head, s_tok;
+  int B, Hq, Hkv, gq;
+  int block_size, bs_shift, max_blocks, num_blocks, max_ctx;
+  int hpw, sub, hgroups, qchunks, tps, nsplit;
+  int lds_bt_bytes;
+  float scale_log2e;
+};
+
+struct DecodePlan {
+  int nw, hpw, sub, hgroups, G, qchunks, tps, nsplit;
+  bool mfma;  // grouped-query shape served by the matrix-core kernel
+  size_t lds_bytes, lds_bt_bytes, ws_bytes;
+};
+
+// Matrix-core decode kernel for grouped-query attention (paged_decode_gqa.hip).
+constexpr int kGqaWaves = 4;       // waves per workgroup
+constexpr int kGqaTokens = 32;     // tokens per wave per pipeline step
+constexpr int kGqaHeads = 16;      // query heads per tile (one MFMA N dimension)
+bool decode_gqa_supported(int dtype, int D, int gq);
+size_t decode_gqa_lds_bytes(int D, int sub, size_t lds_bt_bytes);
+int decode_gqa_launch(const DecodeParams& p, const DecodePlan& pl, int D, int dtype, hipStream_t stream);
+
+}  // namespace mi355

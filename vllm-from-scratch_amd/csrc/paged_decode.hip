@@ -22,37 +22,12 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "decode_params.h"
 
 namespace mi355 {
 namespace {
 
 constexpr int kMaxThreads = 512;
-constexpr int kMaxBtEntries = 8192;  // block-table entries one workgroup may stage in LDS
-constexpr float kNegBig = -1.0e30f;  // running-max start: finite so that exp2(m - m) never sees inf - inf
-
-struct DecodeParams {
-  void* out;
-  const void* q;
-  const void* kc;
-  const void* vc;
-  const int32_t* bt;
-  const int32_t* ctx;
-  const int32_t* cu;  // non-null selects causal mode over packed sequences (see below)
-  int nseq;
-  float* ws_acc;  // [B, Hq, nsplit, D]
-  float* ws_ml;   // [B, Hq, nsplit, 2]  (max in log2 units, sum)
-  int64_t q_stride_seq, s_blk, s_head, s_tok;
-  int B, Hq, Hkv, gq;
-  int block_size, bs_shift, max_blocks, num_blocks, max_ctx;
-  int hpw, sub, hgroups, qchunks, tps, nsplit;
-  int lds_bt_bytes;
-  float scale_log2e;
-};
-
-struct DecodePlan {
-  int nw, hpw, sub, hgroups, G, qchunks, tps, nsplit;
-  size_t lds_bytes, lds_bt_bytes, ws_bytes;
-};
 
 template <class Tag, int D>
 struct Geo {
@@ -338,20 +313,25 @@ int make_plan(int B, int Hq, int Hkv, int D, int block_size, int max_context, in
   if (block_size <= 0) return fail(MI355_EINVAL, "block_size %d", block_size);
   if (max_context < 0) return fail(MI355_EINVAL, "max_context %d", max_context);
   DecodePlan pl;
-  pl.nw = 8;
   const int gq = Hq / Hkv;
-  pl.G = gq >= 8 ? 8 : gq > 2 ? 4 : gq;  // 1, 2, 4 or 8 query heads per wave
+  // Grouped-query shapes (>= 4 query heads per kv head, 16-bit, head_dim 64 / 128) go to the
+  // matrix-core kernel; MI355_DECODE_GQA_MFMA=0 keeps them on the VALU kernel (A/B measurements).
+  pl.mfma = !causal && decode_gqa_supported(dtype, D, gq) && env_int("MI355_DECODE_GQA_MFMA", 1) != 0;
+  pl.nw = pl.mfma ? kGqaWaves : 8;
+  pl.G = pl.mfma ? kGqaHeads : gq >= 8 ? 8 : gq > 2 ? 4 : gq;  // query heads per wave
   pl.qchunks = (gq + pl.G - 1) / pl.G;
   const int lpt = D / elems_per_lane(dtype);
-  const int ts = (kWave / lpt) * steps_for_group(pl.G);
+  const int ts = pl.mfma ? kGqaTokens : (kWave / lpt) * steps_for_group(pl.G);  // tokens per wave per pipeline step
   const int ctx = max_context > 0 ? max_context : 1;
-  const int target = env_int("MI355_PAGED_TARGET_WGS", 256);  // one workgroup per CU before splitting tokens
+  // one 8-wave workgroup per CU, or two 4-wave ones, before tokens are split
+  const int target = env_int("MI355_PAGED_TARGET_WGS", pl.mfma ? 512 : 256);
   // Heads per workgroup.  Eight kv heads per workgroup fetch the eight head tiles of a block
   // (contiguous in the [block][head][row][d] layout) together.  When that leaves CUs idle,
   // fewer heads per workgroup with the freed waves taking token sub-ranges of the same head
   // fills the chip without a second launch: sub-ranges merge through LDS inside the
   // workgroup, token splits across workgroups need the merge kernel and a workspace trip.
-  pl.hpw = (Hkv % 8 == 0) ? 8 : (Hkv % 4 == 0) ? 4 : (Hkv % 2 == 0) ? 2 : 1;
+  pl.hpw = pl.nw;
+  while (pl.hpw > 1 && Hkv % pl.hpw) pl.hpw /= 2;
   const int forced_hpw = env_int("MI355_PAGED_HPW", 0);
   if (forced_hpw > 0 && forced_hpw <= pl.hpw && pl.hpw % forced_hpw == 0) {
     pl.hpw = forced_hpw;
@@ -378,7 +358,8 @@ int make_plan(int B, int Hq, int Hkv, int D, int block_size, int max_context, in
   pl.tps = (int)tps;
   pl.nsplit = (int)ceil_div64(ctx, tps);
   pl.lds_bt_bytes = causal ? 16 : (size_t)((tps / block_size + 2) * 4 + 15) / 16 * 16;
-  pl.lds_bytes = pl.lds_bt_bytes + (pl.sub > 1 ? (size_t)pl.nw * pl.G * (D + 2) * 4 : 0);
+  pl.lds_bytes = pl.mfma ? decode_gqa_lds_bytes(D, pl.sub, pl.lds_bt_bytes)
+                         : pl.lds_bt_bytes + (pl.sub > 1 ? (size_t)pl.nw * pl.G * (D + 2) * 4 : 0);
   pl.ws_bytes = pl.nsplit > 1 ? (size_t)B * Hq * pl.nsplit * (D + 2) * sizeof(float) : 0;
   *plan = pl;
   return 0;
@@ -401,6 +382,22 @@ int launch_decode(const DecodeParams& p, const DecodePlan& pl, hipStream_t strea
     return check_launch("paged_decode_merge_kernel");
   }
   return 0;
+}
+
+template <class Tag, int D>
+int launch_merge(const DecodeParams& p, hipStream_t stream) {
+  const int64_t threads = (int64_t)p.B * p.Hq * (D / 4);
+  hipLaunchKernelGGL((paged_decode_merge_kernel<Tag, D>), dim3((unsigned)ceil_div64(threads, 256)), dim3(256), 0,
+                     stream, p);
+  return check_launch("paged_decode_merge_kernel");
+}
+
+// Matrix-core kernel for grouped-query shapes (+ the shared merge kernel when tokens are split).
+int launch_gqa(const DecodeParams& p, const DecodePlan& pl, int D, int dtype, hipStream_t s) {
+  if (int rc = decode_gqa_launch(p, pl, D, dtype, s)) return rc;
+  if (p.nsplit == 1) return 0;
+  if (dtype == MI355_BF16) return D == 64 ? launch_merge<BF16, 64>(p, s) : launch_merge<BF16, 128>(p, s);
+  return D == 64 ? launch_merge<F16, 64>(p, s) : launch_merge<F16, 128>(p, s);
 }
 
 template <class Tag, int D>
@@ -501,6 +498,7 @@ extern "C" int mi355_paged_decode(void* out, const void* q, int64_t q_stride_seq
   p.lds_bt_bytes = (int)pl.lds_bt_bytes;
   p.scale_log2e = scale * 1.4426950408889634f;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (pl.mfma) return launch_gqa(p, pl, D, dtype, s);
   switch (dtype) {
     case MI355_F32: return dispatch_d<F32>(D, p, pl, s);
     case MI355_BF16: return dispatch_d<BF16>(D, p, pl, s);
