@@ -255,6 +255,29 @@ int mi355_decode_step_inputs(int64_t* token_ids, int64_t* positions, int64_t* sl
                              const int32_t* table_pool, int32_t rows, int32_t pool_rows, int32_t width,
                              int32_t block_size, void* stream);
 
+/*
+ * Attention of several NEW query tokens per sequence over the paged cache, each token attending
+ * to cache positions 0 .. its own position -- what a later chunk of a chunked prompt needs
+ * (the reference's chunked prefill attends within the chunk only, 05_mini_vllm/mini_vllm.py:437-458;
+ * this is the same causal attention with the earlier chunks read through the block table).  The
+ * K/V rows of the new tokens must already be in the cache (mi355_kv_write_slots /
+ * mi355_rope_kv_write).
+ *   segment s (0 <= s < nseg): query tokens are rows seg_q_start[s] .. +seg_len[s]-1 of q / out,
+ *   the first of them sits at position seg_pos0[s] of the sequence whose block table is
+ *   block_tables[s][:]; query j attends to positions 0 .. seg_pos0[s] + j.
+ *   q [T, Hq, D] (q_stride_tok elements between tokens), out [T, Hq, D] contiguous;
+ *   max_q_len >= every seg_len, max_context >= every seg_pos0 + seg_len (host-side bounds).
+ * bf16 / fp16 at head_dim 64 or 128 (matrix-core kernel); other shapes return
+ * MI355_EUNSUPPORTED and the caller runs the tokens as rows of mi355_paged_decode.
+ */
+int mi355_paged_prefill(void* out, const void* q, int64_t q_stride_tok,
+                        const void* k_cache, const void* v_cache, const int32_t* block_tables,
+                        const int32_t* seg_q_start, const int32_t* seg_len, const int32_t* seg_pos0,
+                        int32_t nseg, int32_t max_q_len, int32_t Hq, int32_t Hkv, int32_t D,
+                        int32_t block_size, int32_t max_blocks, int32_t num_blocks, int32_t max_context,
+                        int64_t kv_stride_block, int64_t kv_stride_head, int64_t kv_stride_tok,
+                        float scale, int32_t dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

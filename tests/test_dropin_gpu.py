@@ -435,3 +435,42 @@ def test_engine_prefix_caching_same_tokens_fewer_computed(mv, device):
     assert plain[1]['cached_tokens'] == 0
     assert cached[1]['requests'] == 5 and cached[1]['cached_tokens'] == 4 * 40   # 5 shared blocks x 4 later requests
     assert plain[2] == cached[2] == 128
+
+
+def test_engine_bf16_chunked_prefill_uses_paged_prefill_kernel(mv, device, monkeypatch):
+    """bf16 engine, head_dim 64: later chunks of a chunked prompt go through mi355_paged_prefill
+    (one launch per layer and step, not one paged-decode row per token) and the first generated
+    token's logits stay close to the un-chunked bf16 run and to the fp32 run of the same weights
+    (tolerance: bf16 activations through 2 layers, logits of magnitude ~1)."""
+    from mi355_paged import ops
+    kw = dict(vocab_size=160, hidden_size=256, num_layers=2, num_heads=4, intermediate_size=256,
+              num_kv_blocks=64, block_size=16, max_num_seqs=4, device='cuda')
+    torch.manual_seed(6)
+    ref32 = mv.MiniVLLM(**kw, max_num_batched_tokens=512, enable_chunked_prefill=False)
+    whole = mv.MiniVLLM(**kw, max_num_batched_tokens=512, enable_chunked_prefill=False, dtype=torch.bfloat16)
+    chunked = mv.MiniVLLM(**kw, max_num_batched_tokens=40, enable_chunked_prefill=True, dtype=torch.bfloat16)
+    state = ref32.model.state_dict()
+    for eng in (whole, chunked):
+        eng.model.load_state_dict({k: v for k, v in state.items() if 'cache' not in k}, strict=False)
+    calls = {'append': 0, 'rows': 0}
+    real_append, real_decode = ops.paged_prefill, ops.paged_decode
+    monkeypatch.setattr(ops, 'paged_prefill', lambda *a, **k: calls.__setitem__('append', calls['append'] + 1) or real_append(*a, **k))
+    monkeypatch.setattr(ops, 'paged_decode', lambda *a, **k: calls.__setitem__('rows', calls['rows'] + 1) or real_decode(*a, **k))
+    prompt = [int(x) for x in torch.randint(1, 160, (150,))]
+    logits = {}
+    for name, eng in (('fp32', ref32), ('whole', whole), ('chunked', chunked)):
+        eng.add_request(prompt, max_new_tokens=1, temperature=0.0)
+        f = eng.model.forward_planned
+        cap = []
+        eng.model.forward_planned = lambda *a, _f=f, _c=cap, **k: _c.append(_f(*a, **k)) or _c[-1]
+        steps = 0
+        while eng.scheduler.has_unfinished:
+            eng.step()
+            steps += 1
+        logits[name] = cap[-1].float().cpu()
+        if name == 'chunked':
+            assert steps == 4                                     # 40 + 40 + 40 + 30 tokens
+    assert calls['append'] == 3 * 2 and calls['rows'] == 0        # three later chunks x two layers
+    torch.testing.assert_close(logits['whole'], logits['fp32'], atol=0.08, rtol=0.05)
+    torch.testing.assert_close(logits['chunked'], logits['fp32'], atol=0.08, rtol=0.05)
+    torch.testing.assert_close(logits['chunked'], logits['whole'], atol=0.08, rtol=0.05)

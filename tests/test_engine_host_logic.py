@@ -245,3 +245,21 @@ def test_chunked_prefill_registers_blocks_as_chunks_complete():
         sched.update(items, [4])
         seen.append((a.num_computed_tokens, a.num_registered_blocks))
     assert seen == [(6, 1), (12, 3), (14, 3)]
+
+
+def test_plan_later_chunks_become_append_segments_when_the_kernel_covers_the_model():
+    # request 0: decode at position 7; request 1: later chunk (positions 4..6); request 2: first chunk;
+    # request 3: a one-token later chunk (stays a paged-decode row)
+    positions = [7, 4, 5, 6, 0, 1, 9]
+    args = (positions, [1, 3, 2, 1], [False, True, True, True], [[3, 8], [5, 6], [2], [4, 1, 7]], 'cpu')
+    plan = build_attn_plan(*args, append_ok=True)
+    assert plan.causal_index.tolist() == [4, 5] and plan.cu_seqlens.tolist() == [0, 2]
+    assert plan.paged_index.tolist() == [0, 6] and plan.paged_context.tolist() == [8, 10]
+    assert plan.paged_tables.tolist() == [[3, 8, 0], [4, 1, 7]]
+    assert plan.append_tokens == 3 and plan.append_meta.tolist() == [[1], [3], [4]]
+    assert plan.append_tables.tolist() == [[5, 6]]
+    assert plan.max_append_len == 3 and plan.max_append_context == 7
+    # without the kernel the same tokens are paged-decode rows
+    rows = build_attn_plan(*args)
+    assert rows.append_tokens == 0 and rows.paged_index.tolist() == [0, 1, 2, 3, 6]
+    assert rows.paged_context.tolist() == [8, 5, 6, 7, 10]

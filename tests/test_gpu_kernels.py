@@ -171,6 +171,66 @@ def test_decode_grouped_query_matches_valu_kernel(ops, device, monkeypatch):
     np.testing.assert_allclose(mfma[keep], want, **LOWP_TOL)
 
 
+@pytest.mark.parametrize('shape', [
+    # Hq, Hkv, D, BS, [(pos0, n_query_tokens), ...]
+    (8, 8, 64, 16, [(0, 40), (130, 17), (5, 1), (64, 64)]),          # one head per kv head: 16 tokens per tile
+    (8, 4, 64, 16, [(33, 50), (0, 7)]),                              # 2 heads per kv head: 8 tokens x 2 heads
+    (16, 4, 128, 16, [(100, 35), (7, 3), (256, 16)]),                # 4 x 4
+    (16, 2, 64, 8, [(1000, 21)]),                                    # 8 heads per kv head, long prefix, sub-ranges
+    (12, 4, 64, 16, [(20, 30)]),                                     # 3 heads per kv head -> padded to 4
+    (40, 2, 128, 32, [(50, 9), (0, 33)]),                            # 20 heads per kv head: two head tiles, 1 token
+    (4, 4, 64, 3, [(10, 29)]),                                       # block size not a power of two
+])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('layout', ['NHSD', 'NSHD'])
+def test_paged_prefill_segments(ops, device, shape, dtype, layout):
+    """Several new query tokens per sequence over the paged cache: token j of a segment attends to
+    positions 0 .. pos0 + j.  Checked token by token against the decode oracle with that context."""
+    Hq, Hkv, D, BS, segs = shape
+    rng = np.random.default_rng(hash((Hq, Hkv, D, BS, len(segs))) % (2 ** 31))
+    nseg = len(segs)
+    max_ctx = max(p0 + n for p0, n in segs)
+    per = (max_ctx + BS - 1) // BS
+    NB = nseg * per + 5
+    bt = rng.permutation(NB)[:nseg * per].reshape(nseg, per).astype(np.int32)
+    cache = torch.from_numpy(rng.standard_normal((2, NB, Hkv, BS, D), dtype=np.float32)).to(dtype)
+    T = sum(n for _, n in segs) + 3                                   # 3 rows that belong to no segment
+    q = torch.from_numpy(rng.standard_normal((T, Hq, D), dtype=np.float32)).to(dtype)
+    q0, starts = 2, []                                                # segments start after 2 foreign rows
+    for _, n in segs:
+        starts.append(q0)
+        q0 += n
+    tc = cache.to(device)
+    if layout == 'NSHD':
+        tc = tc.permute(0, 1, 3, 2, 4).contiguous()
+    out = torch.full((T, Hq, D), 7.0, dtype=dtype, device=device)
+    ops.paged_prefill(q.to(device), tc[0], tc[1], torch.from_numpy(bt).to(device),
+                      torch.tensor(starts, dtype=torch.int32, device=device),
+                      torch.tensor([n for _, n in segs], dtype=torch.int32, device=device),
+                      torch.tensor([p0 for p0, _ in segs], dtype=torch.int32, device=device),
+                      max(n for _, n in segs), max_ctx, layout=layout, out=out)
+    got = out.float().cpu().numpy()
+    qn, cn = q.float().numpy(), cache.float().numpy()
+    owned = np.zeros(T, dtype=bool)
+    for s, (p0, n) in enumerate(segs):
+        for j in range(n):
+            row = starts[s] + j
+            owned[row] = True
+            want = orc.paged_decode(qn[row], cn[0], cn[1], bt[s].tolist(), p0 + j + 1, BS, dtype=np.float64)
+            np.testing.assert_allclose(got[row], want, **LOWP_TOL)
+    assert (got[~owned] == 7.0).all()                                 # rows outside every segment are untouched
+
+
+def test_paged_prefill_rejects_unsupported_shapes(ops, device):
+    from mi355_paged._lib import Mi355Error
+    assert ops.paged_prefill_supported(torch.bfloat16, 64) and not ops.paged_prefill_supported(torch.float32, 64)
+    q = torch.zeros(4, 2, 32, dtype=torch.bfloat16, device=device)
+    cache = torch.zeros(2, 2, 16, 32, dtype=torch.bfloat16, device=device)
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=device)
+    with pytest.raises(Mi355Error, match='head_dim'):
+        ops.paged_prefill(q, cache, cache, i32([[0, 1]]), i32([0]), i32([4]), i32([0]), 4, 4)
+
+
 def test_decode_ignores_unused_and_clamps_bad_block_ids(ops, device):
     """Entries of a block-table row past ceil(context/block_size) are never read, whatever they
     hold; ids outside the pool inside the used range are clamped (wrong answer for that row,

@@ -1,4 +1,5 @@
-"""End-to-end MiniVLLM throughput on the GPU (random weights): python tools/bench_engine.py [nseq prompt_len new_tokens]"""
+"""End-to-end MiniVLLM throughput on the GPU (random weights):
+python tools/bench_engine.py [nseq prompt_len new_tokens [token_budget]]   (a budget below the prompt length chunks the prompts)"""
 import os
 import sys
 import time
@@ -7,11 +8,11 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 import torch
 import mini_vllm as mv
 
-nseq, plen, ntok = ([int(x) for x in sys.argv[1:]] + [128, 256, 32])[:3]
+nseq, plen, ntok, budget = ([int(x) for x in sys.argv[1:]] + [128, 256, 32, 8192][len(sys.argv) - 1:])[:4]
 torch.manual_seed(0)
 eng = mv.MiniVLLM(vocab_size=32000, hidden_size=512, num_layers=4, num_heads=8, intermediate_size=1536,
                   num_kv_blocks=nseq * ((plen + ntok) // 16 + 2), block_size=16, max_num_seqs=nseq,
-                  max_num_batched_tokens=8192, device='cuda', dtype=torch.bfloat16)
+                  max_num_batched_tokens=budget, device='cuda', dtype=torch.bfloat16)
 g = torch.Generator().manual_seed(1)
 for _ in range(2):   # first pass warms up kernels / allocator
     for i in range(nseq):

@@ -1,0 +1,35 @@
+"""Sampler kernel timings by mode (HIP events around each call; run under rocprofv3 for kernel times).
+Usage: python tools/bench_sampler.py [batch vocab]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'vllm-from-scratch_amd'))
+import torch
+from mi355_paged import ops
+
+B, V = ([int(x) for x in sys.argv[1:]] + [256, 32000])[:2]
+dev = torch.device('cuda', 0)
+g = torch.Generator(device=dev).manual_seed(1)
+logits = [torch.randn((B, V), generator=g, device=dev) for _ in range(4)]
+temp = torch.full((B,), 0.8, device=dev)
+modes = {
+    'argmax': lambda x: ops.sample_argmax(x),
+    'temperature': lambda x: ops.sample_topk_topp(x, temp, None, None, seed=1),
+    'top_p=0.9': lambda x: ops.sample_topk_topp(x, temp, torch.full((B,), 0.9, device=dev), None, seed=1),
+    'top_p=0.5': lambda x: ops.sample_topk_topp(x, temp, torch.full((B,), 0.5, device=dev), None, seed=1),
+    'top_k=50': lambda x: ops.sample_topk_topp(x, temp, None, torch.full((B,), 50, dtype=torch.int32, device=dev), seed=1),
+    'top_k=50,top_p=0.9': lambda x: ops.sample_topk_topp(x, temp, torch.full((B,), 0.9, device=dev),
+                                                          torch.full((B,), 50, dtype=torch.int32, device=dev), seed=1),
+}
+for name, fn in modes.items():
+    for i in range(5):
+        fn(logits[i % 4])
+    n = 40
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for i in range(n):
+        fn(logits[i % 4])
+    b.record()
+    torch.cuda.synchronize()
+    print(f"B={B} vocab={V} {name}: {a.elapsed_time(b) / n * 1e3:.1f} us per call", flush=True)

@@ -26,6 +26,14 @@ struct DecodeParams {
   int hpw, sub, hgroups, qchunks, tps, nsplit;
   int lds_bt_bytes;
   float scale_log2e;
+  // Append mode of the matrix-core kernel (several query tokens per sequence, each attending to
+  // the cache up to and including its own position): per segment the first row of q / out, the
+  // number of query tokens and the position of the first one; n_qt query tiles per segment of
+  // tq tokens each; a tile's 16 columns are tq tokens x (1 << hgp_shift) heads of the kv group.
+  const int32_t* seg_q0;
+  const int32_t* seg_len;
+  const int32_t* seg_pos0;
+  int n_qt, tq, hgp_shift;
 };
 
 struct DecodePlan {
@@ -41,5 +49,6 @@ constexpr int kGqaHeads = 16;      // query heads per tile (one MFMA N dimension
 bool decode_gqa_supported(int dtype, int D, int gq);
 size_t decode_gqa_lds_bytes(int D, int sub, size_t lds_bt_bytes);
 int decode_gqa_launch(const DecodeParams& p, const DecodePlan& pl, int D, int dtype, hipStream_t stream);
+int append_gqa_launch(const DecodeParams& p, const DecodePlan& pl, int D, int dtype, hipStream_t stream);
 
 }  // namespace mi355

@@ -497,6 +497,8 @@ extern "C" int mi355_paged_decode(void* out, const void* q, int64_t q_stride_seq
   p.nsplit = pl.nsplit;
   p.lds_bt_bytes = (int)pl.lds_bt_bytes;
   p.scale_log2e = scale * 1.4426950408889634f;
+  p.seg_q0 = p.seg_len = p.seg_pos0 = nullptr;
+  p.n_qt = p.tq = p.hgp_shift = 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (pl.mfma) return launch_gqa(p, pl, D, dtype, s);
   switch (dtype) {
@@ -505,6 +507,102 @@ extern "C" int mi355_paged_decode(void* out, const void* q, int64_t q_stride_seq
     case MI355_F16: return dispatch_d<F16>(D, p, pl, s);
   }
   return fail(MI355_EINVAL, "paged_decode: dtype %d", dtype);
+}
+
+extern "C" int mi355_paged_prefill(void* out, const void* q, int64_t q_stride_tok, const void* k_cache,
+                                   const void* v_cache, const int32_t* block_tables, const int32_t* seg_q_start,
+                                   const int32_t* seg_len, const int32_t* seg_pos0, int32_t nseg,
+                                   int32_t max_q_len, int32_t Hq, int32_t Hkv, int32_t D, int32_t block_size,
+                                   int32_t max_blocks, int32_t num_blocks, int32_t max_context,
+                                   int64_t kv_stride_block, int64_t kv_stride_head, int64_t kv_stride_tok,
+                                   float scale, int32_t dtype, void* stream) {
+  if (nseg == 0 || max_q_len == 0) return 0;
+  if (!out || !q || !k_cache || !v_cache || !block_tables || !seg_q_start || !seg_len || !seg_pos0)
+    return fail(MI355_EINVAL, "paged_prefill: null pointer argument");
+  if (nseg < 0 || max_q_len < 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || block_size <= 0 || max_blocks <= 0 ||
+      num_blocks <= 0 || max_context <= 0)
+    return fail(MI355_EINVAL, "paged_prefill: bad shape");
+  const int gq = Hq / Hkv;
+  if (!decode_gqa_supported(dtype, D, 4))
+    return fail(MI355_EUNSUPPORTED, "paged_prefill: 16-bit dtypes at head_dim 64 / 128 only (dtype %d, D %d)", dtype, D);
+  if ((int64_t)max_context > (int64_t)max_blocks * block_size) max_context = max_blocks * block_size;
+  if (kv_stride_block <= 0 || kv_stride_head < 0 || kv_stride_tok <= 0 || kv_stride_block >= (1LL << 31) ||
+      kv_stride_tok >= (1LL << 31) || (int64_t)Hkv * kv_stride_head + D >= (1LL << 31))
+    return fail(MI355_EINVAL, "paged_prefill: kv strides out of range");
+  if (kv_stride_block % 8 || kv_stride_head % 8 || kv_stride_tok % 8 || q_stride_tok % 8 ||
+      q_stride_tok < (int64_t)Hq * D)
+    return fail(MI355_EINVAL, "paged_prefill: strides must keep head rows 16-byte aligned");
+  if (((uintptr_t)out | (uintptr_t)q | (uintptr_t)k_cache | (uintptr_t)v_cache) & 15)
+    return fail(MI355_EINVAL, "paged_prefill: tensors must be 16-byte aligned");
+
+  // Tile columns: tq query tokens x hgp (>= heads of the kv group, power of two, <= 16) heads.
+  int hgp_shift = 0;
+  while ((1 << hgp_shift) < gq && hgp_shift < 4) ++hgp_shift;
+  DecodePlan pl;
+  pl.mfma = true;
+  pl.nw = kGqaWaves;
+  pl.G = kGqaHeads;
+  pl.qchunks = gq > kGqaHeads ? (gq + kGqaHeads - 1) / kGqaHeads : 1;
+  const int tq = kGqaHeads >> hgp_shift;
+  const int n_qt = (max_q_len + tq - 1) / tq;
+  const int64_t tiles = (int64_t)nseg * n_qt;
+  pl.hpw = pl.nw;
+  while (pl.hpw > 1 && Hkv % pl.hpw) pl.hpw /= 2;
+  while (pl.hpw > 1 && tiles * (Hkv / pl.hpw) * pl.qchunks < 512 &&
+         max_context >= 2 * kGqaTokens * (pl.nw / pl.hpw) * 2)
+    pl.hpw /= 2;
+  pl.sub = pl.nw / pl.hpw;
+  pl.hgroups = Hkv / pl.hpw;
+  const int quantum = pl.sub * kGqaTokens;
+  pl.tps = (int)(ceil_div64(max_context, quantum) * quantum);   // no token splits: the tiles already fill the chip
+  pl.nsplit = 1;
+  if ((int64_t)pl.tps / block_size + 2 > kMaxBtEntries)
+    return fail(MI355_EUNSUPPORTED, "paged_prefill: context %d with block_size %d exceeds the staged block table",
+                max_context, block_size);
+  if (tiles * pl.hgroups * pl.qchunks >= (1LL << 31)) return fail(MI355_EINVAL, "paged_prefill: grid too large");
+  pl.lds_bt_bytes = (size_t)((pl.tps / block_size + 2) * 4 + 15) / 16 * 16;
+  pl.lds_bytes = decode_gqa_lds_bytes(D, pl.sub, pl.lds_bt_bytes);
+  pl.ws_bytes = 0;
+
+  DecodeParams p;
+  p.out = out;
+  p.q = q;
+  p.kc = k_cache;
+  p.vc = v_cache;
+  p.bt = block_tables;
+  p.ctx = nullptr;
+  p.cu = nullptr;
+  p.nseq = 0;
+  p.ws_acc = nullptr;
+  p.ws_ml = nullptr;
+  p.q_stride_seq = q_stride_tok;
+  p.s_blk = kv_stride_block;
+  p.s_head = kv_stride_head;
+  p.s_tok = kv_stride_tok;
+  p.B = (int)tiles;
+  p.Hq = Hq;
+  p.Hkv = Hkv;
+  p.gq = gq;
+  p.block_size = block_size;
+  p.bs_shift = ilog2_exact(block_size);
+  p.max_blocks = max_blocks;
+  p.num_blocks = num_blocks;
+  p.max_ctx = max_context;
+  p.hpw = pl.hpw;
+  p.sub = pl.sub;
+  p.hgroups = pl.hgroups;
+  p.qchunks = pl.qchunks;
+  p.tps = pl.tps;
+  p.nsplit = 1;
+  p.lds_bt_bytes = (int)pl.lds_bt_bytes;
+  p.scale_log2e = scale * 1.4426950408889634f;
+  p.seg_q0 = seg_q_start;
+  p.seg_len = seg_len;
+  p.seg_pos0 = seg_pos0;
+  p.n_qt = n_qt;
+  p.tq = tq;
+  p.hgp_shift = hgp_shift;
+  return append_gqa_launch(p, pl, D, dtype, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int mi355_prefill_causal(void* out, const void* q, const void* k, const void* v,

@@ -63,7 +63,11 @@ struct Mma16<F16> {
   }
 };
 
-template <class Tag, int D>
+// APPEND = false: one query token per sequence, a tile's 16 columns are query heads of one kv
+// head (decode).  APPEND = true: a tile's columns are tq query tokens of one segment x the
+// (padded) heads of the kv group, column by column limited to its own causal context; the
+// segment's new K/V rows are already in the cache (chunked prompt processing).
+template <class Tag, int D, bool APPEND>
 __global__ void __launch_bounds__(kGqaWaves* kWave, 2) paged_decode_gqa_kernel(const DecodeParams p) {
   constexpr int KS = D / 32;          // MFMA k-steps over head_dim
   constexpr int OT = D / 16;          // 16-dim tiles of the output
@@ -91,7 +95,26 @@ __global__ void __launch_bounds__(kGqaWaves* kWave, 2) paged_decode_gqa_kernel(c
   const int sp = bid % p.nsplit;
   const int b = bid / p.nsplit;
 
-  const int ctx = max(0, min(p.ctx[b], p.max_ctx));
+  // Tile geometry: context the workgroup walks, and this lane's column (query row, head, limit).
+  int ctx, qrow = b, bt_row = b, head_in_group = qc * kGqaHeads + c, col_limit;
+  bool col_ok;
+  if constexpr (APPEND) {
+    const int seg = b / p.n_qt, qt = b - seg * p.n_qt;
+    const int slen = p.seg_len[seg], tok0 = qt * p.tq;
+    if (tok0 >= slen) return;
+    const int ntok = min(p.tq, slen - tok0), pos0 = p.seg_pos0[seg];
+    const int ctok = c >> p.hgp_shift, chd = c & ((1 << p.hgp_shift) - 1);
+    ctx = max(0, min(pos0 + tok0 + ntok, p.max_ctx));          // context of the tile's last query token
+    col_limit = min(pos0 + tok0 + ctok + 1, ctx);               // causal: a query sees positions <= its own
+    head_in_group = p.hgp_shift == 4 ? qc * kGqaHeads + chd : chd;
+    col_ok = ctok < ntok && head_in_group < p.gq;
+    qrow = p.seg_q0[seg] + tok0 + min(ctok, ntok - 1);
+    bt_row = seg;
+  } else {
+    ctx = max(0, min(p.ctx[b], p.max_ctx));
+    col_limit = ctx;
+    col_ok = head_in_group < p.gq;
+  }
   const int t0 = sp * p.tps;
   if (p.nsplit > 1 && t0 >= ctx) return;  // the merge kernel skips splits past the context
   const int wg_end = min(ctx, t0 + p.tps);
@@ -101,7 +124,7 @@ __global__ void __launch_bounds__(kGqaWaves* kWave, 2) paged_decode_gqa_kernel(c
   const int lb0 = block_of(t0);
   const int nlb = wg_end > t0 ? block_of(wg_end - 1) - lb0 + 1 : 0;
   for (int i = tid; i < nlb; i += blockDim.x) {
-    const int id = p.bt[(int64_t)b * p.max_blocks + lb0 + i];
+    const int id = p.bt[(int64_t)bt_row * p.max_blocks + lb0 + i];
     s_bt[i] = min(max(id, 0), p.num_blocks - 1);
   }
   __syncthreads();
@@ -111,14 +134,14 @@ __global__ void __launch_bounds__(kGqaWaves* kWave, 2) paged_decode_gqa_kernel(c
   const int len_w = p.tps / p.sub;
   const int tw0 = t0 + sb * len_w;
   const int tw1 = min(wg_end, tw0 + len_w);
-  const int hq0 = kvh * p.gq + qc * kGqaHeads;
-  const bool head_ok = qc * kGqaHeads + c < p.gq;   // this lane's query head (column c of the tile) exists
+  const int hq = kvh * p.gq + min(head_in_group, p.gq - 1);   // this lane's query head (column c of the tile)
+  const bool head_ok = col_ok;
 
-  // Query fragments (B operand): lane (c, g), k-step s holds Q[head c][32s + 8g .. +8).
+  // Query fragments (B operand): lane (c, g), k-step s holds Q[column c][32s + 8g .. +8).
   u32x4 qf[KS];
   {
     const char* src = static_cast<const char*>(p.q) +
-                      ((int64_t)b * p.q_stride_seq + (int64_t)(hq0 + c) * D + 8 * g) * 2;
+                      ((int64_t)qrow * p.q_stride_seq + (int64_t)hq * D + 8 * g) * 2;
 #pragma unroll
     for (int s = 0; s < KS; ++s)
       qf[s] = head_ok ? *reinterpret_cast<const u32x4*>(src + s * 64) : u32x4{0u, 0u, 0u, 0u};
@@ -134,6 +157,7 @@ __global__ void __launch_bounds__(kGqaWaves* kWave, 2) paged_decode_gqa_kernel(c
   const int lrow = lane / CPR, lchunk = lane % CPR;   // this lane's (row within an instruction, chunk)
   const uint32_t lane_off = (uint32_t)kvh * (uint32_t)p.s_head + lchunk * 8;  // host checks it fits
   const int nsteps = tw1 > tw0 ? (tw1 - tw0 + kGqaTokens - 1) / kGqaTokens : 0;
+  const int lim = min(tw1, col_limit);   // first token this lane's column does not attend to
 
   // Load instruction i of a step covers rows i*RPI .. i*RPI + RPI - 1 of the 32-token tile,
   // 16 bytes per lane, consecutive lanes on consecutive bytes of a row.
@@ -180,7 +204,7 @@ __global__ void __launch_bounds__(kGqaWaves* kWave, 2) paged_decode_gqa_kernel(c
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float v = (ts0 + 16 * u + 4 * g + j < tw1) ? st[u][j] * p.scale_log2e : -__builtin_inff();
+        const float v = (ts0 + 16 * u + 4 * g + j < lim) ? st[u][j] * p.scale_log2e : -__builtin_inff();
         s[4 * u + j] = v;
         mx = fmaxf(mx, v);
       }
@@ -267,17 +291,16 @@ __global__ void __launch_bounds__(kGqaWaves* kWave, 2) paged_decode_gqa_kernel(c
     }
   }
   if (sb != 0 || !head_ok) return;
-  const int hq = hq0 + c;
   if (p.nsplit == 1) {
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
-    char* dst = static_cast<char*>(p.out) + (((int64_t)b * p.Hq + hq) * D + 4 * g) * 2;
+    char* dst = static_cast<char*>(p.out) + (((int64_t)qrow * p.Hq + hq) * D + 4 * g) * 2;
 #pragma unroll
     for (int i = 0; i < OT; ++i) {
       const f32x4 v = o[i] * inv;
       *reinterpret_cast<u32x2*>(dst + i * 32) = u32x2{Mma16<Tag>::pack2(v[0], v[1]), Mma16<Tag>::pack2(v[2], v[3])};
     }
   } else {
-    const int64_t rec = ((int64_t)b * p.Hq + hq) * p.nsplit + sp;
+    const int64_t rec = ((int64_t)qrow * p.Hq + hq) * p.nsplit + sp;
     float* dst = p.ws_acc + rec * D + 4 * g;
 #pragma unroll
     for (int i = 0; i < OT; ++i) *reinterpret_cast<f32x4*>(dst + 16 * i) = o[i];
@@ -288,12 +311,19 @@ __global__ void __launch_bounds__(kGqaWaves* kWave, 2) paged_decode_gqa_kernel(c
   }
 }
 
-template <class Tag, int D>
+template <class Tag, int D, bool APPEND>
 int launch(const DecodeParams& p, const DecodePlan& pl, hipStream_t stream) {
   const int64_t grid = (int64_t)p.B * p.nsplit * p.hgroups * p.qchunks;
-  hipLaunchKernelGGL((paged_decode_gqa_kernel<Tag, D>), dim3((unsigned)grid), dim3(kGqaWaves * kWave), pl.lds_bytes,
-                     stream, p);
-  return check_launch("paged_decode_gqa_kernel");
+  hipLaunchKernelGGL((paged_decode_gqa_kernel<Tag, D, APPEND>), dim3((unsigned)grid), dim3(kGqaWaves * kWave),
+                     pl.lds_bytes, stream, p);
+  return check_launch(APPEND ? "paged_decode_gqa_kernel (append)" : "paged_decode_gqa_kernel");
+}
+
+template <bool APPEND>
+int launch_any(const DecodeParams& p, const DecodePlan& pl, int D, int dtype, hipStream_t stream) {
+  if (dtype == MI355_BF16)
+    return D == 64 ? launch<BF16, 64, APPEND>(p, pl, stream) : launch<BF16, 128, APPEND>(p, pl, stream);
+  return D == 64 ? launch<F16, 64, APPEND>(p, pl, stream) : launch<F16, 128, APPEND>(p, pl, stream);
 }
 
 }  // namespace
@@ -309,8 +339,11 @@ size_t decode_gqa_lds_bytes(int D, int sub, size_t lds_bt_bytes) {
 }
 
 int decode_gqa_launch(const DecodeParams& p, const DecodePlan& pl, int D, int dtype, hipStream_t stream) {
-  if (dtype == MI355_BF16) return D == 64 ? launch<BF16, 64>(p, pl, stream) : launch<BF16, 128>(p, pl, stream);
-  return D == 64 ? launch<F16, 64>(p, pl, stream) : launch<F16, 128>(p, pl, stream);
+  return launch_any<false>(p, pl, D, dtype, stream);
+}
+
+int append_gqa_launch(const DecodeParams& p, const DecodePlan& pl, int D, int dtype, hipStream_t stream) {
+  return launch_any<true>(p, pl, D, dtype, stream);
 }
 
 }  // namespace mi355

@@ -51,6 +51,25 @@ def _stream(dev: torch.device) -> int:
     return torch.cuda.current_stream(dev).cuda_stream
 
 
+class _NoSwitch:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
+def _on(dev: torch.device):
+    """Context in which `dev` is the current HIP device; free when it already is (the usual
+    case: torch's device guard costs several microseconds per call)."""
+    if dev.index is None or torch.cuda.current_device() == dev.index:
+        return _NO_SWITCH
+    return torch.cuda.device(dev)
+
+
 def _workspace(dev: torch.device, nbytes: int) -> Tuple[Optional[torch.Tensor], int]:
     """A per-device scratch tensor that only ever grows (torch owns the memory)."""
     if nbytes == 0:
@@ -116,7 +135,7 @@ def paged_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
     code = dtype_code(q)
     if scale is None:
         scale = 1.0 / math.sqrt(D)
-    with torch.cuda.device(dev):
+    with _on(dev):
         need = lib.mi355_paged_decode_workspace_bytes(B, Hq, g['heads'], D, g['block_size'],
                                                       int(max_context), code)
         ws, ws_bytes = _workspace(dev, need)
@@ -157,7 +176,7 @@ def kv_write_slots(k_cache: torch.Tensor, v_cache: torch.Tensor, k: torch.Tensor
     slots = slots.contiguous()
     if slots.numel() != T:
         raise ValueError("one slot per token expected")
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = lib.mi355_kv_write_slots(
             k_cache.data_ptr(), v_cache.data_ptr(), k.data_ptr(), v.data_ptr(), slots.data_ptr(),
             T, H, D, _stride(k, 0), g['block_size'], g['num_blocks'], g['s_block'], g['s_head'],
@@ -192,7 +211,7 @@ def prefill_causal(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_seqlens
     out = torch.empty((T, Hq, D), dtype=q.dtype, device=dev)
     if scale is None:
         scale = 1.0 / math.sqrt(D)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = lib.mi355_prefill_causal(
             out.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), _stride(q, 0), _stride(k, 0),
             cu_seqlens.data_ptr(), cu_seqlens.numel() - 1, T, int(max_seqlen), Hq, Hkv, D,
@@ -212,7 +231,7 @@ def sample_argmax(logits: torch.Tensor, out: Optional[torch.Tensor] = None) -> t
     B, V = logits.shape
     if out is None:
         out = torch.empty((B,), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = lib.mi355_sample_argmax(out.data_ptr(), logits.data_ptr(), B, V, _stride(logits, 0),
                                      dtype_code(logits), _stream(dev))
     _lib.check(rc, 'mi355_sample_argmax')
@@ -238,7 +257,7 @@ def sample_topk_topp(logits: torch.Tensor, temperature: torch.Tensor,
         top_k = top_k.to(torch.int32).contiguous()
     out = torch.empty((B,), dtype=torch.int32, device=dev)
     probs = torch.empty((B, V), dtype=torch.float32, device=dev) if return_probs else None
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = lib.mi355_sample_topk_topp(
             out.data_ptr(), logits.data_ptr(), temperature.data_ptr(),
             top_p.data_ptr() if top_p is not None else None,
@@ -260,7 +279,7 @@ def slot_mapping(block_tables: torch.Tensor, starts: torch.Tensor, cu_tokens: to
             raise TypeError("block_tables, starts and cu_tokens must be int32")
     block_tables = block_tables.contiguous()
     out = torch.empty((total_tokens,), dtype=torch.int64, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = lib.mi355_slot_mapping(out.data_ptr(), block_tables.data_ptr(),
                                     starts.contiguous().data_ptr(), cu_tokens.contiguous().data_ptr(),
                                     block_tables.shape[0], block_tables.shape[1], int(block_size),
@@ -302,7 +321,7 @@ def mla_decode(q: torch.Tensor, c_kv: torch.Tensor, k_rope: torch.Tensor, cos: t
         raise TypeError("context_lens / row_seq must be int32")
     out = torch.empty((rows, H, R), dtype=torch.float32, device=dev)
     code = dtype_code(q)
-    with torch.cuda.device(dev):
+    with _on(dev):
         need = lib.mi355_mla_decode_workspace_bytes(rows, H, R, P, int(max_context), code)
         ws, ws_bytes = _workspace(dev, need)
         rc = lib.mi355_mla_decode(
@@ -363,7 +382,7 @@ def rope_kv_write(q: torch.Tensor, k: torch.Tensor, v: Optional[torch.Tensor], c
             raise TypeError("slots must be int64 [T]")
         slots = slots.contiguous()
         v_stride = _stride(v, 0)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = lib.mi355_rope_kv_write(
             q.data_ptr(), k.data_ptr(), v.data_ptr() if slots is not None else None,
             _stride(q, 0), _stride(k, 0), v_stride, cos_table.data_ptr(), sin_table.data_ptr(),
@@ -393,7 +412,7 @@ def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float, delta: Optional[t
         if tuple(delta.shape) != (T, hidden) or delta.dtype != x.dtype or delta.stride(1) != 1:
             raise ValueError("delta must match x")
         total = torch.empty((T, hidden), dtype=x.dtype, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = lib.mi355_rmsnorm(out.data_ptr(), total.data_ptr() if total is not None else None, x.data_ptr(),
                                _stride(x, 0), delta.data_ptr() if delta is not None else None,
                                _stride(delta, 0) if delta is not None else 0, weight.data_ptr(), float(eps),
@@ -411,7 +430,7 @@ def silu_mul(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
         raise ValueError("gate and up must be [T, width] of one dtype with contiguous rows")
     T, width = gate.shape
     out = torch.empty((T, width), dtype=gate.dtype, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = lib.mi355_silu_mul(out.data_ptr(), gate.data_ptr(), _stride(gate, 0), up.data_ptr(), _stride(up, 0),
                                 T, width, dtype_code(gate), _stream(dev))
     _lib.check(rc, 'mi355_silu_mul')
@@ -431,9 +450,58 @@ def decode_step_inputs(packed: torch.Tensor, table_pool: torch.Tensor, block_siz
     i64 = torch.empty((3, rows), dtype=torch.int64, device=dev)
     ctx = torch.empty((rows,), dtype=torch.int32, device=dev)
     tables = torch.empty((rows, width), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = lib.mi355_decode_step_inputs(i64[0].data_ptr(), i64[1].data_ptr(), i64[2].data_ptr(), ctx.data_ptr(),
                                           tables.data_ptr(), packed.data_ptr(), table_pool.data_ptr(), rows,
                                           table_pool.shape[0], width, int(block_size), _stream(dev))
     _lib.check(rc, 'mi355_decode_step_inputs')
     return i64[0], i64[1], i64[2], ctx, tables
+
+
+def paged_prefill_supported(dtype: torch.dtype, head_dim: int) -> bool:
+    """Shapes mi355_paged_prefill serves (the matrix-core kernel); others go row by row through
+    paged_decode.  MI355_PAGED_PREFILL=0 forces the row path (A/B measurements)."""
+    import os
+    return (dtype in (torch.bfloat16, torch.float16) and head_dim in (64, 128)
+            and os.environ.get('MI355_PAGED_PREFILL', '1') != '0')
+
+
+def paged_prefill(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, block_tables: torch.Tensor,
+                  seg_q_start: torch.Tensor, seg_len: torch.Tensor, seg_pos0: torch.Tensor, max_q_len: int,
+                  max_context: int, layout: str = 'NHSD', scale: Optional[float] = None,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Causal attention of new query tokens over the paged cache (their K/V rows already written).
+
+    q [T, Hq, D]; segment s owns rows seg_q_start[s] .. +seg_len[s]-1, its first token sits at
+    position seg_pos0[s] and reads the cache through block_tables[s]; all three int32 [nseg].
+    Rows of `out` [T, Hq, D] outside every segment are left untouched."""
+    dev = require_device(q, k_cache, v_cache, block_tables, seg_q_start, seg_len, seg_pos0)
+    lib = _lib.load()
+    q = _head_rows(q)
+    T, Hq, D = q.shape
+    g = _kv_geometry(k_cache, layout)
+    if tuple(v_cache.shape) != tuple(k_cache.shape) or _kv_geometry(v_cache, layout) != g:
+        raise ValueError("k_cache and v_cache must share shape and strides")
+    if k_cache.dtype != q.dtype or v_cache.dtype != q.dtype or g['head_dim'] != D:
+        raise TypeError("query and KV cache must share dtype and head_dim")
+    for t in (block_tables, seg_q_start, seg_len, seg_pos0):
+        if t.dtype != torch.int32:
+            raise TypeError("block_tables and the segment vectors must be int32")
+    nseg = seg_len.numel()
+    block_tables = block_tables.contiguous()
+    if block_tables.dim() != 2 or block_tables.shape[0] != nseg or seg_q_start.numel() != nseg \
+            or seg_pos0.numel() != nseg:
+        raise ValueError("block_tables must be [nseg, max_blocks]; the segment vectors [nseg]")
+    if out is None:
+        out = torch.empty((T, Hq, D), dtype=q.dtype, device=dev)
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    with _on(dev):
+        rc = lib.mi355_paged_prefill(
+            out.data_ptr(), q.data_ptr(), _stride(q, 0), k_cache.data_ptr(), v_cache.data_ptr(),
+            block_tables.data_ptr(), seg_q_start.contiguous().data_ptr(), seg_len.contiguous().data_ptr(),
+            seg_pos0.contiguous().data_ptr(), nseg, int(max_q_len), Hq, g['heads'], D, g['block_size'],
+            block_tables.shape[1], g['num_blocks'], int(max_context), g['s_block'], g['s_head'], g['s_tok'],
+            float(scale), dtype_code(q), _stream(dev))
+    _lib.check(rc, 'mi355_paged_prefill')
+    return out

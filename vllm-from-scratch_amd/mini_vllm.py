@@ -430,9 +430,12 @@ class AttnPlan:
     """Which kernel serves which token of a flattened step.
 
     Prompt segments that start at position 0 go through the causal prefill kernel
-    (they only need their own fresh K/V).  Every other token -- decode tokens and
-    later chunks of a chunked prompt -- becomes one row of a paged-decode launch
-    with its own context length and block table.
+    (they only need their own fresh K/V).  Decode tokens are rows of a paged-decode
+    launch with their own context length and block table.  Later chunks of a chunked
+    prompt (and prompts that start after a cached prefix) are "append" segments of one
+    paged-prefill launch: every token attends to the cache up to its own position; where
+    that kernel does not cover the model's dtype / head_dim their tokens are paged-decode
+    rows instead.
     """
     total_tokens: int
     causal_index: Optional[torch.Tensor]      # int64 [Tc] token ids served by causal prefill (None = all)
@@ -444,16 +447,24 @@ class AttnPlan:
     paged_context: Optional[torch.Tensor]     # int32 [R]
     paged_rows: int
     max_context: int
+    append_tokens: int = 0                            # tokens served by the paged-prefill kernel
+    append_tables: Optional[torch.Tensor] = None      # int32 [nseg, max_blocks]
+    append_meta: Optional[torch.Tensor] = None        # int32 [3, nseg]: first token row, length, first position
+    max_append_len: int = 0
+    max_append_context: int = 0
 
 
 def build_attn_plan(positions: Sequence[int], seq_lens: Sequence[int], is_prefill: Sequence[bool],
                     block_tables: Optional[Sequence[Sequence[int]]], device,
                     reference_compat: bool = False,
                     device_tables: Optional[DeviceBlockTables] = None,
-                    table_rows: Optional[Sequence[int]] = None) -> AttnPlan:
+                    table_rows: Optional[Sequence[int]] = None,
+                    append_ok: bool = False) -> AttnPlan:
     """block_tables: per-request lists of block ids (host), or None for the reference's
     semantics.  When device_tables / table_rows are given (one row id per request) the paged
-    rows' tables are gathered on the device instead of being rebuilt from the host lists."""
+    rows' tables are gathered on the device instead of being rebuilt from the host lists.
+    append_ok: the paged-prefill kernel covers this model, so prompt chunks that do not start
+    at position 0 become append segments instead of one paged-decode row per token."""
     causal_tok: List[int] = []
     cu = [0]
     max_len = 0
@@ -461,6 +472,9 @@ def build_attn_plan(positions: Sequence[int], seq_lens: Sequence[int], is_prefil
     paged_ctx: List[int] = []
     paged_tab: List[Sequence[int]] = []
     paged_row: List[int] = []
+    app_meta: List[List[int]] = [[], [], []]
+    app_tab: List[Sequence[int]] = []
+    app_row: List[int] = []
     use_rows = device_tables is not None and table_rows is not None and not reference_compat
     compat = reference_compat or (block_tables is None and not use_rows)
     tok = 0
@@ -476,6 +490,14 @@ def build_attn_plan(positions: Sequence[int], seq_lens: Sequence[int], is_prefil
             paged_tok.append(tok)
             paged_ctx.append(1)
             paged_tab.append((0,))
+        elif prefill and append_ok and n_q > 1:
+            app_meta[0].append(tok)
+            app_meta[1].append(n_q)
+            app_meta[2].append(start)
+            if use_rows:
+                app_row.append(table_rows[r])
+            else:
+                app_tab.append(block_tables[r])
         elif use_rows:
             for j in range(n_q):
                 paged_tok.append(tok + j)
@@ -510,6 +532,17 @@ def build_attn_plan(positions: Sequence[int], seq_lens: Sequence[int], is_prefil
             rows = [list(t) + [0] * (width - len(t)) for t in paged_tab]
             plan.paged_tables = torch.tensor(rows, dtype=torch.int32, device=device)
         plan.paged_context = torch.tensor(paged_ctx, dtype=torch.int32, device=device)
+    if app_meta[0]:
+        plan.append_tokens = sum(app_meta[1])
+        plan.max_append_len = max(app_meta[1])
+        plan.max_append_context = max(p0 + n for p0, n in zip(app_meta[2], app_meta[1]))
+        plan.append_meta = torch.tensor(app_meta, dtype=torch.int32, device=device)
+        if app_row:
+            plan.append_tables = device_tables.gather(app_row)
+        else:
+            width = max(len(t) for t in app_tab)
+            plan.append_tables = torch.tensor([list(t) + [0] * (width - len(t)) for t in app_tab],
+                                              dtype=torch.int32, device=device)
     return plan
 
 
@@ -547,7 +580,7 @@ def paged_attention_step(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, k_ca
         if sel is None:
             out = part
         else:
-            out = torch.empty_like(q)
+            out = torch.empty(q.shape, dtype=q.dtype, device=dev)
             out[sel] = part
     if plan.paged_rows:
         sel = plan.paged_index
@@ -557,8 +590,14 @@ def paged_attention_step(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, k_ca
             out = part
         else:
             if out is None:
-                out = torch.empty_like(q)
+                out = torch.empty(q.shape, dtype=q.dtype, device=dev)
             out[sel] = part
+    if plan.append_tokens:
+        if out is None:
+            out = torch.empty(q.shape, dtype=q.dtype, device=dev)
+        meta = plan.append_meta
+        ops.paged_prefill(q, kc, vc, plan.append_tables, meta[0], meta[1], meta[2], plan.max_append_len,
+                          plan.max_append_context, layout='NSHD', scale=scale, out=out)
     return out.to(home)
 
 
@@ -732,8 +771,11 @@ class MiniTransformer(nn.Module):
         token_ids, positions, slot_mapping = (t.to(home) for t in (token_ids, positions, slot_mapping))
         if positions_host is None:
             positions_host = positions.tolist()
+        head_dim = self.k_cache.shape[-1]
+        append_ok = self.k_cache.is_cuda and ops.paged_prefill_supported(self.k_cache.dtype, head_dim)
         plan = build_attn_plan(positions_host, seq_lens, is_prefill, block_tables,
-                               _compute_device(self.k_cache), reference_compat, device_tables, table_rows)
+                               _compute_device(self.k_cache), reference_compat, device_tables, table_rows,
+                               append_ok=append_ok)
         last, offset = [], 0
         for n in seq_lens:
             offset += n
