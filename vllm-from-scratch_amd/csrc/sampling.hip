@@ -11,6 +11,7 @@ namespace mi355 {
 namespace {
 
 constexpr int kMaxWaves = 16;
+constexpr int kCandCap = 1024;   // cut-search candidates one workgroup may park in LDS (16 per lane of one wave)
 
 template <int CTRL>
 __device__ __forceinline__ int dpp_i(int v) {
@@ -199,6 +200,10 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
   __shared__ Exchange xch;
   __shared__ float s_scan[kMaxWaves];
   __shared__ int s_pick;
+  // candidates of the narrowed cut search (values only; see the filter section)
+  __shared__ float s_cand[kCandCap];
+  __shared__ int s_ncand;
+  __shared__ uint32_t s_cut;
   int slot = 0;
   const int tid = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
   const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
@@ -303,11 +308,62 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
     float pmax = 0.f;
     for_each([&](float q, int) { pmax = fmaxf(pmax, q); });
     pmax = block_reduce(pmax, fmaxop, xch, slot);
+    // Two phases.  Whole-row passes (every thread compares all of its elements) narrow [lo, hi]
+    // until at most kCandCap elements have their value inside it; those are parked in LDS and
+    // one wave finishes the bisection on them alone, adding the (mass, count) already known to
+    // lie above hi.  The count inside the interval costs nothing: it is the difference of the
+    // counts the two bounds were set with.
     uint32_t lo = 0u, hi = __builtin_bit_cast(uint32_t, pmax);
-    while (lo < hi) {
+    FC a_hi = {0.f, 0};          // (mass, count) strictly above hi
+    int n_ge_lo = vocab;         // elements with value >= lo
+    while (lo < hi && n_ge_lo - a_hi.c > kCandCap) {
       const uint32_t mid = lo + ((hi - lo) >> 1);
       const FC a = above(__builtin_bit_cast(float, mid));
-      if (a.f < tp && a.c < kk) hi = mid; else lo = mid + 1;
+      if (a.f < tp && a.c < kk) {
+        hi = mid;
+        a_hi = a;
+      } else {
+        lo = mid + 1;
+        n_ge_lo = a.c;
+      }
+    }
+    if (lo < hi) {
+      if (tid == 0) s_ncand = 0;
+      __syncthreads();
+      const float flo = __builtin_bit_cast(float, lo), fhi = __builtin_bit_cast(float, hi);
+      for_each([&](float q, int) {
+        if (q >= flo && q <= fhi) {
+          const int slot_i = atomicAdd(&s_ncand, 1);
+          if (slot_i < kCandCap) s_cand[slot_i] = q;
+        }
+      });
+      __syncthreads();
+      const int ncand = min(s_ncand, kCandCap);
+      if (wave == 0) {
+        // the wave's share of the candidates moves into registers once; -1 marks an empty slot
+        constexpr int kPerLane = kCandCap / kWave;
+        float cq[kPerLane];
+#pragma unroll
+        for (int i = 0; i < kPerLane; ++i) cq[i] = (lane + i * kWave < ncand) ? s_cand[lane + i * kWave] : -1.0f;
+        while (lo < hi) {
+          const uint32_t mid = lo + ((hi - lo) >> 1);
+          const float v = __builtin_bit_cast(float, mid);
+          float mf = 0.f;
+          int mc = 0;
+#pragma unroll
+          for (int i = 0; i < kPerLane; ++i) {
+            const bool up = cq[i] > v;
+            mf += up ? cq[i] : 0.f;
+            mc += up ? 1 : 0;
+          }
+          mf = wave_reduce(mf, addf) + a_hi.f;
+          mc = wave_reduce(mc, addi) + a_hi.c;
+          if (mf < tp && mc < kk) hi = mid; else lo = mid + 1;
+        }
+        if (lane == 0) s_cut = lo;
+      }
+      __syncthreads();
+      lo = s_cut;
     }
     const float u = __builtin_bit_cast(float, lo);
     float vmin = __builtin_inff();
@@ -399,11 +455,12 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
 template <class Tag>
 int launch_sample(const SampleParams& p, int B, hipStream_t s) {
   const int v = p.vocab;
-  // Register-resident rows up to 32768 entries (512 threads may use 256 VGPRs each,
-  // 1024 threads only 128); longer rows are recomputed from the logits on every pass.
+  // Register-resident rows up to 32768 entries (1024 threads x 32 values: 16 waves per CU hide
+  // the latency of the dependent reduction chains better than 512 x 64); longer rows are
+  // recomputed from the logits on every pass.
   if (v <= 4 * 256) hipLaunchKernelGGL((sample_kernel<Tag, 4, 256>), dim3(B), dim3(256), 0, s, p);
   else if (v <= 16 * 1024) hipLaunchKernelGGL((sample_kernel<Tag, 16, 1024>), dim3(B), dim3(1024), 0, s, p);
-  else if (v <= 64 * 512) hipLaunchKernelGGL((sample_kernel<Tag, 64, 512>), dim3(B), dim3(512), 0, s, p);
+  else if (v <= 32 * 1024) hipLaunchKernelGGL((sample_kernel<Tag, 32, 1024>), dim3(B), dim3(1024), 0, s, p);
   else hipLaunchKernelGGL((sample_kernel<Tag, 0, 1024>), dim3(B), dim3(1024), 0, s, p);
   return check_launch("sample_kernel");
 }
