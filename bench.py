@@ -12,7 +12,9 @@ One step = one decode step of one attention layer for the whole batch:
   (1) write the new token's K/V rows into their slots   (mi355_kv_write_slots)
   (2) paged decode attention over the 2048-token context (mi355_paged_decode)
   (3) greedy sampling from fp32 logits [256, 32000]      (mi355_sample_argmax)
-  (4) with N > 1: all-gather of the sampled ids across ranks (RCCL)
+  (4) with N > 1: all-gather of the sampled ids across ranks (RCCL), asynchronous: ranks do
+      not need each other's ids to go on decoding, so step i's collective overlaps step i+1;
+      every collective has completed before the timed region closes
 `value` = sequences (= tokens) decoded per second over all ranks.  `roofline`
 prices step (2), the dominant kernel, against HBM bandwidth using the
 algorithmic byte count; `cpu_baseline` times the reference-shaped CPU decode
@@ -147,7 +149,7 @@ def main():
     inp = build_inputs(cfg, device, seed=rank, sets=2 if args.config == 'metric' else 4)
     nsets = len(inp['pools'])
     out = torch.empty((B, H, D), dtype=torch.bfloat16, device=device)
-    ids = torch.empty((B,), dtype=torch.int32, device=device)
+    gather = dp.OverlappedTokenGather(B, device)
 
     ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -160,8 +162,8 @@ def main():
         ops.paged_decode(inp['q'], kc, vc, bt, inp['ctx'], S, layout='NHSD', out=out)
         if timed:
             ev_b[i].record()
-        ops.sample_argmax(inp['logits'], out=ids)
-        return dp.all_gather_token_ids(ids, total=B * world)
+        ops.sample_argmax(inp['logits'], out=gather.send_buffer(i))
+        gather.launch(i)
 
     def barrier():
         if world > 1:
@@ -171,19 +173,21 @@ def main():
     trace('inputs built')
     for i in range(args.warmup):
         step(i, False)
+    gather.drain()
     trace('warmup issued')
     barrier()
     trace('timed region')
     t0 = time.perf_counter()
     for i in range(args.steps):
-        gathered = step(i, True)
+        step(i, True)
+    gather.drain()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert gathered.numel() == B * world
+    assert gather.result(args.steps - 1).numel() == B * world
 
     kernel_ms = sorted(a.elapsed_time(b) for a, b in zip(ev_a, ev_b))
     avg_ms = sum(kernel_ms) / len(kernel_ms)

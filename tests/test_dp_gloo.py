@@ -49,3 +49,42 @@ def test_all_gather_world2_matches_single_process(tmp_path, total):
     want = torch.arange(100, 100 + total, dtype=torch.int32)
     for r in range(2):
         assert torch.equal(torch.load(tmp_path / f'r{r}.pt'), want)
+
+
+def _overlap_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        n, steps = 5, 7
+        g = dp.OverlappedTokenGather(n, 'cpu')
+        seen = []
+        for i in range(steps):
+            buf = g.send_buffer(i)
+            buf.copy_(torch.arange(n, dtype=torch.int32) + 100 * rank + 1000 * i)   # this step's "sampled ids"
+            g.launch(i)
+            if i >= 1:
+                seen.append(g.result(i - 1).clone())        # the previous step's ids, one step late
+        seen.append(g.result(steps - 1).clone())
+        g.drain()
+        torch.save(torch.stack(seen), os.path.join(out_dir, f'o{rank}.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_gather_world2_returns_every_step_in_rank_order(tmp_path):
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(_overlap_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    want = torch.stack([torch.cat([torch.arange(5, dtype=torch.int32) + 100 * r + 1000 * i for r in range(2)])
+                        for i in range(7)])
+    for r in range(2):
+        assert torch.equal(torch.load(tmp_path / f'o{r}.pt'), want)
+
+
+def test_overlapped_gather_single_process_passthrough():
+    g = dp.OverlappedTokenGather(3, 'cpu')
+    g.send_buffer(0).copy_(torch.tensor([4, 5, 6], dtype=torch.int32))
+    g.launch(0)
+    assert g.result(0).tolist() == [4, 5, 6]
+    g.drain()

@@ -61,3 +61,59 @@ def all_gather_token_ids(local_ids: torch.Tensor, total: Optional[int] = None,
     if all(s == widest for s in sizes):
         return recv
     return torch.cat([recv[r * widest:r * widest + s] for r, s in enumerate(sizes)])
+
+
+class OverlappedTokenGather:
+    """All-gather of every step's sampled ids that does not stall the step after it.
+
+    Ranks never need each other's ids to continue decoding (the gathered vector feeds the
+    front end), so step i's collective may still be in flight while step i + 1 computes.  Two
+    send / receive buffer pairs alternate: `send_buffer(i)` is where step i's sampler writes
+    (first waiting, on the stream, for the collective of step i - 2 that used the same pair),
+    `launch(i)` starts the asynchronous all-gather, `result(i)` / `drain()` wait for it.
+    With the nccl (= RCCL) backend waiting is a stream dependency, not a host block.
+    Equal shard sizes only (pad the local batch otherwise).  Without a process group, or on a
+    single rank, the local ids are the result.
+    """
+
+    def __init__(self, n_local: int, device, dtype=torch.int32, group=None):
+        self.group = group
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.world = dist.get_world_size(group) if self.active else 1
+        # gloo cannot move device memory: stage through the host, synchronously (CPU tests, rehearsals)
+        self.host_staged = self.active and dist.get_backend(group) == 'gloo' and torch.device(device).type == 'cuda'
+        self.send = [torch.zeros((n_local,), dtype=dtype, device=device) for _ in range(2)]
+        self.recv = [torch.zeros((n_local * self.world,), dtype=dtype, device=device) if self.active else None
+                     for _ in range(2)]
+        self.work = [None, None]
+
+    def send_buffer(self, step: int) -> torch.Tensor:
+        self._wait(step & 1)
+        return self.send[step & 1]
+
+    def launch(self, step: int) -> None:
+        slot = step & 1
+        if not self.active:
+            return
+        if self.host_staged:
+            out = torch.empty((self.recv[slot].numel(),), dtype=self.recv[slot].dtype)
+            dist.all_gather_into_tensor(out, self.send[slot].cpu(), group=self.group)
+            self.recv[slot].copy_(out)
+            return
+        self.work[slot] = dist.all_gather_into_tensor(self.recv[slot], self.send[slot], group=self.group,
+                                                      async_op=True)
+
+    def _wait(self, slot: int) -> None:
+        if self.work[slot] is not None:
+            self.work[slot].wait()
+            self.work[slot] = None
+
+    def result(self, step: int) -> torch.Tensor:
+        """Gathered ids of `step` (valid until send_buffer(step + 2) is requested)."""
+        slot = step & 1
+        self._wait(slot)
+        return self.recv[slot] if self.active else self.send[slot]
+
+    def drain(self) -> None:
+        self._wait(0)
+        self._wait(1)
