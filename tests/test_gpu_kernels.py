@@ -311,6 +311,35 @@ def test_decode_metric_shape_subset_bf16(ops, device):
     np.testing.assert_allclose(out2.float().cpu().numpy()[0], out[3], **LOWP_TOL)
 
 
+def test_decode_grouped_query_large_shape_properties(ops, device):
+    """A serving-size grouped-query batch (64 sequences x 4096 tokens, 32 query / 8 kv heads,
+    D=128, bf16; 1 GiB of KV) through the matrix-core kernel: a subset of rows against the
+    float64 oracle, and the size-independent properties -- batch order does not matter (bit for
+    bit), a longer block table / larger max_context bound does not change a row, and the split
+    path (forced by a small batch) agrees with the unsplit one within tolerance."""
+    B, S, Hq, Hkv, D, BS = 64, 4096, 32, 8, 128, 16
+    g = torch.Generator(device=device).manual_seed(3)
+    per = S // BS
+    NB = B * per + 11
+    kc = torch.randn((NB, Hkv, BS, D), generator=g, device=device).to(torch.bfloat16)
+    vc = torch.randn((NB, Hkv, BS, D), generator=g, device=device).to(torch.bfloat16)
+    q = torch.randn((B, Hq, D), generator=g, device=device).to(torch.bfloat16)
+    bt = torch.randperm(NB, generator=g, device=device)[:B * per].view(B, per).to(torch.int32)
+    ctx = torch.randint(S // 2, S + 1, (B,), generator=g, device=device, dtype=torch.int32)
+    ctx[0] = S
+    out = ops.paged_decode(q, kc, vc, bt, ctx, S)
+    kcf, vcf = kc.float().cpu().numpy(), vc.float().cpu().numpy()
+    for b in (0, 9, 63):
+        want = orc.paged_decode(q[b].float().cpu().numpy(), kcf, vcf, bt[b].tolist(), int(ctx[b]), BS, dtype=np.float64)
+        np.testing.assert_allclose(out[b].float().cpu().numpy(), want, **LOWP_TOL)
+    perm = torch.randperm(B, generator=g, device=device)
+    assert torch.equal(ops.paged_decode(q[perm], kc, vc, bt[perm], ctx[perm], S), out[perm])
+    wide = torch.cat([bt, torch.zeros((B, 40), dtype=torch.int32, device=device)], dim=1)
+    assert torch.equal(ops.paged_decode(q, kc, vc, wide, ctx, S), out)
+    few = ops.paged_decode(q[:3], kc, vc, bt[:3], ctx[:3], S)            # 3 sequences: tokens are split
+    torch.testing.assert_close(few.float(), out[:3].float(), **LOWP_TOL)
+
+
 def test_decode_bad_arguments(ops, device):
     from mi355_paged._lib import Mi355Error
     q = torch.zeros((1, 8, 48), device=device)

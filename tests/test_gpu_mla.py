@@ -29,7 +29,7 @@ def ops():
 @pytest.mark.parametrize('shape', [
     # seqs, H, R, P, max_ctx
     (3, 4, 32, 8, 40), (2, 8, 64, 16, 100), (2, 16, 128, 32, 333), (2, 16, 512, 64, 700),
-    (1, 20, 256, 64, 50), (1, 128, 512, 64, 130), (5, 3, 32, 24, 17),
+    (1, 20, 256, 64, 50), (1, 128, 512, 64, 130), (5, 3, 32, 24, 17), (3, 16, 128, 24, 450), (2, 9, 256, 8, 300),
 ])
 def test_mla_decode_kernel(ops, device, shape, dtype):
     seqs, H, R, P, max_ctx = shape
@@ -63,6 +63,30 @@ def test_mla_decode_config4_shape(ops, device):
     out = ops.mla_decode(q.to(device), c_kv.to(device), k_rope.to(device), torch.from_numpy(cos).to(device),
                          torch.from_numpy(sin).to(device), torch.from_numpy(ctx).to(device), S, (128 + 64) ** -0.5)
     np.testing.assert_allclose(out.cpu().numpy(), want, **TOL[torch.bfloat16])
+
+
+def test_mla_decode_large_shape_properties(ops, device):
+    """Config-4 geometry at serving size (64 rows x 4096 tokens, kv_lora_rank 512, rope 64, bf16):
+    rows against the float64 oracle, row order does not matter (bit for bit), and a row read
+    through row_seq from another position of the cache tensor gives the same bits."""
+    rows, H, R, P, S = 64, 16, 512, 64, 4096
+    g = torch.Generator(device=device).manual_seed(8)
+    q = (torch.randn((rows, H, R + P), generator=g, device=device) * 0.3).to(torch.bfloat16)
+    c_kv = torch.randn((rows, S, R), generator=g, device=device).to(torch.bfloat16)
+    k_rope = torch.randn((rows, S, P), generator=g, device=device).to(torch.bfloat16)
+    ctx = torch.randint(S // 2, S + 1, (rows,), generator=g, device=device, dtype=torch.int32)
+    ctx[5] = S
+    cos, sin = mo.rope_tables(P, S)
+    cosd, sind = torch.from_numpy(cos).to(device), torch.from_numpy(sin).to(device)
+    scale = (128 + 64) ** -0.5
+    out = ops.mla_decode(q, c_kv, k_rope, cosd, sind, ctx, S, scale)
+    pick = [0, 5, 63]
+    want = mo.latent_attention(q[pick].float().cpu().numpy(), c_kv[pick].float().cpu().numpy(),
+                               k_rope[pick].float().cpu().numpy(), cos, sin, ctx[pick].cpu().numpy(), scale)
+    np.testing.assert_allclose(out[pick].cpu().numpy(), want, **TOL[torch.bfloat16])
+    perm = torch.randperm(rows, generator=g, device=device)
+    out_perm = ops.mla_decode(q[perm], c_kv, k_rope, cosd, sind, ctx[perm], S, scale, row_seq=perm.to(torch.int32))
+    assert torch.equal(out_perm, out[perm])
 
 
 def test_mla_causal_rows_of_one_sequence(ops, device):
