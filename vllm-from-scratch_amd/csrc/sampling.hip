@@ -11,7 +11,9 @@ namespace mi355 {
 namespace {
 
 constexpr int kMaxWaves = 16;
-constexpr int kCandCap = 1024;   // cut-search candidates one workgroup may park in LDS (16 per lane of one wave)
+constexpr int kCandCapMax = 1024;   // cut-search candidates one workgroup may park in LDS
+constexpr int kHistShift = 19;   // histogram key = probability bit pattern >> 19: exponent + 4 mantissa bits
+constexpr int kHistBins = 2048;  // keys of values in [0, 1] stay below 0x3F800000 >> 19 = 2032
 
 template <int CTRL>
 __device__ __forceinline__ int dpp_i(int v) {
@@ -200,10 +202,15 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
   __shared__ Exchange xch;
   __shared__ float s_scan[kMaxWaves];
   __shared__ int s_pick;
-  // candidates of the narrowed cut search (values only; see the filter section)
+  // cut search state (see the filter section)
+  __shared__ unsigned long long s_hist[kHistBins];
+  __shared__ unsigned long long s_above;
+  constexpr int kCandCap = kCandCapMax;
   __shared__ float s_cand[kCandCap];
-  __shared__ int s_ncand;
-  __shared__ uint32_t s_cut;
+  __shared__ int s_cand_i[kCandCap];
+  __shared__ int s_cutbin;
+  __shared__ float s_res_f[2];
+  __shared__ int s_res_i[3];
   int slot = 0;
   const int tid = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
   const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
@@ -217,6 +224,7 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
   auto addf = [](float a, float c) { return a + c; };
   auto addi = [](int a, int c) { return a + c; };
   auto maxi = [](int a, int c) { return max(a, c); };
+  auto mini = [](int a, int c) { return min(a, c); };
 
   // p = softmax(x / T): the division comes first, as in the reference.  Register-resident
   // rows are divided and exponentiated exactly once.
@@ -302,24 +310,85 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
     kept_mass = block_reduce(s, addf, xch, slot);
   } else {
     const int kk = tk > 0 ? tk : 0x7fffffff;
-    // A value v survives (its first copy in descending order is kept) iff the mass
-    // strictly above it is < top_p and fewer than k elements are above it.  That
-    // predicate is monotone in v, so bisect on the bit pattern of a non-negative float.
+    // A value v survives (its first copy in descending order is kept) iff the mass strictly
+    // above it is < top_p and fewer than k elements are above it: ok(mass, count).  That
+    // predicate is monotone in v, so the smallest surviving bit pattern can be bracketed and
+    // bisected.  Four stages, every sum in a fixed order (results repeat run to run):
+    //  1. histogram of the row over the top 12 bits of the probability's bit pattern (one
+    //     LDS atomic per element: count and fixed-point mass packed in 64 bits) -> the bin
+    //     that holds the cut, with the exact (mass, count) above that bin;
+    //  2. whole-row bisection passes only while more than kCandCap elements sit in the bracket;
+    //  3. those elements (value, index) are parked in LDS in (thread, element) order;
+    //  4. one wave finishes on the candidates alone: bisection, the smallest kept value, the
+    //     ties at that value and which of them (lowest indices first) stay.
+    auto ok = [&](float mass, int count) { return mass < tp && count < kk; };
     float pmax = 0.f;
     for_each([&](float q, int) { pmax = fmaxf(pmax, q); });
     pmax = block_reduce(pmax, fmaxop, xch, slot);
-    // Two phases.  Whole-row passes (every thread compares all of its elements) narrow [lo, hi]
-    // until at most kCandCap elements have their value inside it; those are parked in LDS and
-    // one wave finishes the bisection on them alone, adding the (mass, count) already known to
-    // lie above hi.  The count inside the interval costs nothing: it is the difference of the
-    // counts the two bounds were set with.
-    uint32_t lo = 0u, hi = __builtin_bit_cast(uint32_t, pmax);
-    FC a_hi = {0.f, 0};          // (mass, count) strictly above hi
-    int n_ge_lo = vocab;         // elements with value >= lo
+    const uint32_t pmax_bits = __builtin_bit_cast(uint32_t, pmax);
+
+    // ---- 1. histogram
+    for (int i = tid; i < kHistBins; i += nt) s_hist[i] = 0ull;
+    __syncthreads();
+    for_each([&](float q, int) {
+      const uint32_t key = __builtin_bit_cast(uint32_t, q) >> kHistShift;     // q in [0, 1] -> key < kHistBins
+      atomicAdd(&s_hist[key], (1ull << 41) + (unsigned long long)(q * 1099511627776.0f));   // count | q * 2^40
+    });
+    __syncthreads();
+    if (wave == 0) {
+      // lane l owns bins [l * kPer, (l + 1) * kPer); suffix sums over the lanes above it, then a walk
+      // down its own bins for the lowest one whose "everything above this bin" still passes ok()
+      constexpr int kPer = kHistBins / kWave;
+      unsigned long long own = 0ull;
+#pragma unroll 4
+      for (int i = 0; i < kPer; ++i) own += s_hist[lane * kPer + i];
+      unsigned long long incl = own;    // inclusive suffix scan: lanes >= l
+#pragma unroll
+      for (int off = 1; off < kWave; off <<= 1) {
+        const unsigned long long o = __shfl_down(incl, off);
+        if (lane + off < kWave) incl += o;
+      }
+      unsigned long long run = incl - own;   // sum of the bins above this lane's range
+      int best = 0x7fffffff;
+#pragma unroll 2
+      for (int i = kPer - 1; i >= 0; --i) {
+        const int b = lane * kPer + i;
+        const float mass = (float)(run & ((1ull << 41) - 1)) * 0x1p-40f;
+        if (ok(mass, (int)(run >> 41))) best = b;       // everything above bin b passes: b is a candidate cut bin
+        run += s_hist[b];
+      }
+      best = wave_reduce(best, mini);
+      if (lane == 0) s_cutbin = best;
+    }
+    __syncthreads();
+    int cutbin = s_cutbin;
+    if (cutbin == 0x7fffffff) cutbin = (int)(pmax_bits >> kHistShift);   // nothing passes (top_p <= 0): top bin
+    cutbin = min(cutbin, (int)(pmax_bits >> kHistShift));
+    // (mass, count) strictly above the cut bin, exact: integer sums of the histogram
+    if (wave == 0) {
+      constexpr int kPer = kHistBins / kWave;
+      unsigned long long part = 0ull;
+#pragma unroll 4
+      for (int i = 0; i < kPer; ++i) {
+        const int b = lane * kPer + i;
+        part += b > cutbin ? s_hist[b] : 0ull;
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
+      if (lane == 0) s_above = part;
+    }
+    __syncthreads();
+    const unsigned long long packed_above = s_above;
+    uint32_t lo = (uint32_t)cutbin << kHistShift;
+    uint32_t hi = min((((uint32_t)cutbin + 1u) << kHistShift) - 1u, pmax_bits);
+    FC a_hi = {(float)(packed_above & ((1ull << 41) - 1)) * 0x1p-40f, (int)(packed_above >> 41)};   // strictly above hi
+    int n_ge_lo = a_hi.c + (int)(s_hist[cutbin] >> 41);                                            // elements >= lo
+
+    // ---- 2. whole-row passes while the bracket holds too many elements
     while (lo < hi && n_ge_lo - a_hi.c > kCandCap) {
       const uint32_t mid = lo + ((hi - lo) >> 1);
       const FC a = above(__builtin_bit_cast(float, mid));
-      if (a.f < tp && a.c < kk) {
+      if (ok(a.f, a.c)) {
         hi = mid;
         a_hi = a;
       } else {
@@ -327,75 +396,154 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
         n_ge_lo = a.c;
       }
     }
-    if (lo < hi) {
-      if (tid == 0) s_ncand = 0;
-      __syncthreads();
-      const float flo = __builtin_bit_cast(float, lo), fhi = __builtin_bit_cast(float, hi);
-      for_each([&](float q, int) {
+
+    // ---- 3. candidates = elements with value in [lo, hi], in (thread, element) order
+    const float flo = __builtin_bit_cast(float, lo), fhi = __builtin_bit_cast(float, hi);
+    int mine_n = 0;
+    for_each([&](float q, int) { mine_n += (q >= flo && q <= fhi) ? 1 : 0; });
+    int incl_n = mine_n;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const int o = __shfl_up(incl_n, off);
+      if (lane >= off) incl_n += o;
+    }
+    if (lane == kWave - 1) xch.c[slot][wave] = incl_n;
+    __syncthreads();
+    int base_n = 0, total_n = 0;
+    for (int w = 0; w < nw; ++w) {
+      const int c = xch.c[slot][w];
+      base_n += w < wave ? c : 0;
+      total_n += c;
+    }
+    slot ^= 1;
+    {
+      int at = base_n + incl_n - mine_n;
+      for_each([&](float q, int i) {
         if (q >= flo && q <= fhi) {
-          const int slot_i = atomicAdd(&s_ncand, 1);
-          if (slot_i < kCandCap) s_cand[slot_i] = q;
+          if (at < kCandCap) {
+            s_cand[at] = q;
+            s_cand_i[at] = i;
+          }
+          ++at;
         }
       });
-      __syncthreads();
-      const int ncand = min(s_ncand, kCandCap);
-      if (wave == 0) {
-        // the wave's share of the candidates moves into registers once; -1 marks an empty slot
-        constexpr int kPerLane = kCandCap / kWave;
-        float cq[kPerLane];
+    }
+    __syncthreads();
+    const int ncand = min(total_n, kCandCap);   // total_n <= kCandCap unless lo == hi with many equal values
+
+    // ---- 4. one wave finishes on the candidates
+    if (wave == 0) {
+      // The candidates stay in LDS and are re-read on every use (a fixed number of independent reads
+      // per lane that pipeline; holding them in registers next to the thread's slice of the row
+      // overflows the 128-register budget of 1024 threads).  -1 stands for an empty slot.
+      constexpr int kPerLane = kCandCap / kWave;
+      auto cand = [&](int i) {
+        asm volatile("" ::: "memory");   // keep the read where it is used
+        const int at = lane + i * kWave;
+        return at < ncand ? s_cand[at] : -1.0f;
+      };
+      auto cand_above = [&](float v) {   // (mass, count) of all row elements strictly above v, v inside the bracket
+        float mf = 0.f;
+        int mc = 0;
 #pragma unroll
-        for (int i = 0; i < kPerLane; ++i) cq[i] = (lane + i * kWave < ncand) ? s_cand[lane + i * kWave] : -1.0f;
-        while (lo < hi) {
-          const uint32_t mid = lo + ((hi - lo) >> 1);
-          const float v = __builtin_bit_cast(float, mid);
-          float mf = 0.f;
-          int mc = 0;
-#pragma unroll
-          for (int i = 0; i < kPerLane; ++i) {
-            const bool up = cq[i] > v;
-            mf += up ? cq[i] : 0.f;
-            mc += up ? 1 : 0;
-          }
-          mf = wave_reduce(mf, addf) + a_hi.f;
-          mc = wave_reduce(mc, addi) + a_hi.c;
-          if (mf < tp && mc < kk) hi = mid; else lo = mid + 1;
+        for (int i = 0; i < kPerLane; ++i) {
+          const float c = cand(i);
+          const bool up = c > v;
+          mf += up ? c : 0.f;
+          mc += up ? 1 : 0;
         }
-        if (lane == 0) s_cut = lo;
+        FC r;
+        r.f = wave_reduce(mf, addf) + a_hi.f;
+        r.c = wave_reduce(mc, addi) + a_hi.c;
+        return r;
+      };
+      while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        const FC a = cand_above(__builtin_bit_cast(float, mid));
+        if (ok(a.f, a.c)) hi = mid; else lo = mid + 1;
       }
-      __syncthreads();
-      lo = s_cut;
-    }
-    const float u = __builtin_bit_cast(float, lo);
-    float vmin = __builtin_inff();
-    for_each([&](float q, int) {
-      if (q >= u) vmin = fminf(vmin, q);
-    });
-    vstar = block_reduce(vmin, fminop, xch, slot);
-    const FC a = above(vstar);
-    int ties = 0;
-    for_each([&](float q, int) { ties += (q == vstar); });
-    ties = block_reduce(ties, addi, xch, slot);
-    // Number of tied copies kept: copy j (0-based) needs mass_above + j*v < top_p and count_above + j < k.
-    int keep = ties;
-    if (tp < 1.0f && vstar > 0.f) {
-      int jp = (int)fminf(ceilf((tp - a.f) / vstar), 2.0e9f);
-      while (jp > 0 && !(a.f + (float)(jp - 1) * vstar < tp)) --jp;
-      while (jp < ties && (a.f + (float)jp * vstar < tp)) ++jp;
-      keep = min(keep, jp);
-    }
-    if (tk > 0) keep = min(keep, kk - a.c);
-    keep = max(keep, a.c == 0 ? 1 : 0);
-    if (keep < ties) {
-      // Keep the `keep` lowest-index copies: smallest X with #(ties at index < X) >= keep.
-      int xl = 1, xh = vocab;
-      while (xl < xh) {
-        const int xm = xl + ((xh - xl) >> 1);
-        int c = 0;
-        for_each([&](float q, int i) { c += (q == vstar && i < xm); });
-        c = block_reduce(c, addi, xch, slot);
-        if (c >= keep) xh = xm; else xl = xm + 1;
+      const float u = __builtin_bit_cast(float, lo);
+      // smallest kept value = smallest candidate >= u (when the bracket collapsed onto one value with more
+      // copies than the candidate buffer holds, every copy equals that value)
+      float vmin = total_n > kCandCap ? fhi : __builtin_inff();
+      int ties_n = 0;
+#pragma unroll
+      for (int i = 0; i < kPerLane; ++i) {
+        const float c = cand(i);
+        if (c >= u) vmin = fminf(vmin, c);
       }
-      tie_end = xl;
+      vmin = wave_reduce(vmin, fminop);
+      if (vmin == __builtin_inff()) vmin = fhi;    // no candidate at or above u: cut at the bracket's top
+      const FC a = cand_above(vmin);
+#pragma unroll
+      for (int i = 0; i < kPerLane; ++i) ties_n += (cand(i) == vmin) ? 1 : 0;
+      ties_n = wave_reduce(ties_n, addi);
+      // Number of tied copies kept: copy j (0-based) needs mass_above + j*v < top_p and count_above + j < k.
+      const bool whole_row = total_n > kCandCap;      // more copies of one value than the buffer holds
+      int keep_n = ties_n, cut_index = vocab;
+      if (!whole_row) {
+        if (tp < 1.0f && vmin > 0.f) {
+          int jp = (int)fminf(ceilf((tp - a.f) / vmin), 2.0e9f);
+          while (jp > 0 && !(a.f + (float)(jp - 1) * vmin < tp)) --jp;
+          while (jp < ties_n && (a.f + (float)jp * vmin < tp)) ++jp;
+          keep_n = min(keep_n, jp);
+        }
+        if (tk > 0) keep_n = min(keep_n, kk - a.c);
+        keep_n = max(keep_n, a.c == 0 ? 1 : 0);
+        if (keep_n < ties_n) {
+          // keep the keep_n lowest-index copies: smallest X with #(ties at index < X) >= keep_n
+          int xl = 1, xh = vocab;
+          while (xl < xh) {
+            const int xm = xl + ((xh - xl) >> 1);
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < kPerLane; ++i) {
+              const bool tied = cand(i) == vmin;
+              c += (tied && s_cand_i[lane + i * kWave] < xm) ? 1 : 0;
+            }
+            c = wave_reduce(c, addi);
+            if (c >= keep_n) xh = xm; else xl = xm + 1;
+          }
+          cut_index = xl;
+        }
+      }
+      if (lane == 0) {
+        s_res_f[0] = vmin;
+        s_res_f[1] = a.f;
+        s_res_i[0] = a.c;
+        s_res_i[1] = whole_row ? -1 : keep_n;   // -1: ties are counted and cut over the whole row
+        s_res_i[2] = cut_index;
+      }
+    }
+    __syncthreads();
+    vstar = s_res_f[0];
+    const FC a = {s_res_f[1], s_res_i[0]};
+    int keep = s_res_i[1];
+    tie_end = s_res_i[2];
+    if (keep < 0) {
+      int t = 0;
+      for_each([&](float q, int) { t += (q == vstar); });
+      const int ties = block_reduce(t, addi, xch, slot);
+      keep = ties;
+      if (tp < 1.0f && vstar > 0.f) {
+        int jp = (int)fminf(ceilf((tp - a.f) / vstar), 2.0e9f);
+        while (jp > 0 && !(a.f + (float)(jp - 1) * vstar < tp)) --jp;
+        while (jp < ties && (a.f + (float)jp * vstar < tp)) ++jp;
+        keep = min(keep, jp);
+      }
+      if (tk > 0) keep = min(keep, kk - a.c);
+      keep = max(keep, a.c == 0 ? 1 : 0);
+      if (keep < ties) {
+        int xl = 1, xh = vocab;
+        while (xl < xh) {
+          const int xm = xl + ((xh - xl) >> 1);
+          int c = 0;
+          for_each([&](float q, int i) { c += (q == vstar && i < xm); });
+          c = block_reduce(c, addi, xch, slot);
+          if (c >= keep) xh = xm; else xl = xm + 1;
+        }
+        tie_end = xl;
+      }
     }
     kept_mass = a.f + (float)keep * vstar;
   }
