@@ -547,6 +547,55 @@ def test_sampling_filters_match_oracle(ops, device, vocab):
         assert abs(probs[b].sum() - 1.0) < 1e-4
 
 
+@pytest.mark.parametrize('vocab', [64, 3000, 32000, 40000])
+def test_sampling_ties_at_the_cut_keep_lowest_indices(ops, device, vocab):
+    """Rows built so that the cut falls inside a run of EQUAL probabilities: of the tied tokens the
+    lowest indices are kept (the stable descending order of the oracle), for top-p, top-k and
+    both, including a row where one value has more copies than the kernel's candidate buffer."""
+    rng = np.random.default_rng(vocab + 1)
+    rows, temps, top_ps, top_ks = [], [], [], []
+
+    def add(x, t, p, k):
+        rows.append(x.astype(np.float32)); temps.append(t); top_ps.append(p); top_ks.append(k)
+
+    base = (rng.standard_normal(vocab) * 2).astype(np.float32)
+    x = base.copy()
+    tied = rng.choice(vocab, size=min(12, vocab // 4), replace=False)
+    x[tied] = np.float32(1.5)                                    # a dozen equal logits in the upper tail
+    add(x, 1.0, 0.6, 0)
+    add(x, 1.0, 1.0, int((x > 1.5).sum()) + 5)                    # top-k cuts through the ties
+    add(x, 0.7, 0.8, int((x > 1.5).sum()) + 3)
+    y = np.full(vocab, -3.0, dtype=np.float32)                    # thousands of copies of one value
+    y[rng.choice(vocab, size=3, replace=False)] = 2.0
+    add(y, 1.0, 0.9, 0)
+    add(y, 1.0, 1.0, max(4, vocab // 2))
+    add(np.zeros(vocab, dtype=np.float32), 1.0, 0.5, 0)           # uniform row: keep the first half
+    logits = np.stack(rows)
+    ids, probs = ops.sample_topk_topp(torch.from_numpy(logits).to(device), torch.tensor(temps, device=device),
+                                      torch.tensor(top_ps, device=device),
+                                      torch.tensor(top_ks, dtype=torch.int32, device=device),
+                                      seed=5, return_probs=True)
+    probs = probs.cpu().numpy()
+    for b in range(len(rows)):
+        want, kept = orc.nucleus_probs(logits[b], temps[b], top_ps[b], top_ks[b])
+        got_kept = probs[b] > 0
+        diff = np.nonzero(got_kept != kept)[0]
+        # The oracle's float32 running sum over thousands of equal terms carries rounding of its own
+        # (the kernel evaluates mass_above + j * value instead), so the NUMBER of tied copies kept may
+        # differ by a fraction of a percent; which copies are kept may not: always the lowest indices.
+        cut_value = logits[b][diff[0]] if len(diff) else None
+        n_tied = int((logits[b] == cut_value).sum()) if len(diff) else 0
+        assert len(diff) <= max(1, n_tied // 500), f"row {b}: kept sets differ at {diff[:10]} ({got_kept.sum()} vs {kept.sum()})"
+        if len(diff):
+            assert (logits[b][diff] == cut_value).all()
+            tied_idx = np.nonzero(logits[b] == cut_value)[0]
+            n_kept = int(got_kept[tied_idx].sum())
+            assert got_kept[tied_idx[:n_kept]].all() and not got_kept[tied_idx[n_kept:]].any()
+        if len(diff) == 0:
+            np.testing.assert_allclose(probs[b], want, rtol=2e-4, atol=1e-7)
+        assert got_kept[int(ids[b])]
+
+
 def test_sampling_distribution(ops, device):
     """Draws follow the filtered distribution (chi-square style bound on 20k draws)."""
     vocab, n = 16, 20000
