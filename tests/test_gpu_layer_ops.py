@@ -204,3 +204,38 @@ def test_decode_step_inputs_bit_exact(ops, device):
     t, p, s, c, bt = ops.decode_step_inputs(packed, torch.from_numpy(pool).to(device), 12)
     assert s.tolist() == [-1 if q < 0 or q // 12 >= width else int(pool[r][q // 12]) * 12 + q % 12
                           for q, r in zip(pos.tolist(), row.tolist())]
+
+
+def test_captured_decode_keeps_its_own_workspace(ops, device):
+    """A split-KV decode captured in a HIP graph must not depend on the shared scratch tensor: that
+    tensor is replaced when a later call needs more, and the graph would then write into freed memory."""
+    rng = np.random.default_rng(2)
+    B, H, D, BS, S = 2, 8, 64, 16, 4096                    # 2 sequences: tokens are split, a workspace is needed
+    per = S // BS
+    NB = B * per + 3
+    kc = torch.from_numpy(rng.standard_normal((NB, H, BS, D), dtype=np.float32)).to(torch.bfloat16).to(device)
+    vc = torch.from_numpy(rng.standard_normal((NB, H, BS, D), dtype=np.float32)).to(torch.bfloat16).to(device)
+    q = torch.from_numpy(rng.standard_normal((B, H, D), dtype=np.float32)).to(torch.bfloat16).to(device)
+    bt = torch.from_numpy(rng.permutation(NB)[:B * per].reshape(B, per).astype(np.int32)).to(device)
+    ctx = torch.tensor([S, S - 77], dtype=torch.int32, device=device)
+    want = ops.paged_decode(q, kc, vc, bt, ctx, S).clone()
+    out = torch.empty_like(want)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.paged_decode(q, kc, vc, bt, ctx, S, out=out)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ops.paged_decode(q, kc, vc, bt, ctx, S, out=out)
+    # force the shared scratch to be replaced by a much larger one, and scribble over fresh allocations
+    need = ops._workspaces[device].numel() if device in ops._workspaces else 0
+    big_q = torch.zeros((64, 64, D), dtype=torch.bfloat16, device=device)
+    big_bt = bt[:1].repeat(64, 1)
+    ops.paged_decode(big_q, kc, vc, big_bt, torch.full((64,), 64, dtype=torch.int32, device=device), S)
+    ops._workspaces.pop(device, None)
+    junk = [torch.full((1 << 20,), 1e30, device=device) for _ in range(8)]
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want) and need >= 0 and len(junk) == 8

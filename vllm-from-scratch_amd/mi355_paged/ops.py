@@ -71,9 +71,16 @@ def _on(dev: torch.device):
 
 
 def _workspace(dev: torch.device, nbytes: int) -> Tuple[Optional[torch.Tensor], int]:
-    """A per-device scratch tensor that only ever grows (torch owns the memory)."""
+    """A per-device scratch tensor that only ever grows (torch owns the memory).
+
+    While a HIP graph is being captured the scratch comes from the capture's own memory pool
+    instead: a captured launch keeps the raw pointer, and the shared tensor may be replaced by a
+    larger one (and freed) long before the graph is replayed."""
     if nbytes == 0:
         return None, 0
+    if torch.cuda.is_current_stream_capturing():
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        return ws, ws.numel()
     ws = _workspaces.get(dev)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)

@@ -1010,10 +1010,10 @@ class MiniVLLM:
                 self._device_tables = DeviceBlockTables(_compute_device(self.model.k_cache),
                                                         rows=max(8, self.scheduler.max_num_seqs))
             rows = self._device_tables.sync(requests)
-        as_long = dict(dtype=torch.long, device=self.device)
+        # one host-to-device copy for the three per-token vectors (the reference makes three, :737-739)
+        step_inputs = torch.tensor([tokens, positions, slots], dtype=torch.long, device=self.device)
         with torch.no_grad():
-            logits = self.model(torch.tensor(tokens, **as_long), torch.tensor(positions, **as_long),
-                                torch.tensor(slots, **as_long), seq_lens, prefill_flags,
+            logits = self.model(step_inputs[0], step_inputs[1], step_inputs[2], seq_lens, prefill_flags,
                                 positions_host=positions, reference_compat=self.reference_compat,
                                 device_tables=self._device_tables, table_rows=rows)
         next_tokens = self.sampler.sample(logits, requests)
