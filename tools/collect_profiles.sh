@@ -17,7 +17,11 @@ step kernel trace of bench.py
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_bench" -o bench -- \
   python3 bench.py --steps 100 --no-cpu-baseline > "$OUT/bench_line_under_rocprof.json" 2> "$OUT/trace_bench.log"
 
-step kernel trace of the MLA and prefill benches
+step kernel trace of the small decode config, the grouped-query, MLA and prefill benches
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c2" -o c2 -- \
+  python3 tools/tune_decode.py c2 256 > "$OUT/c2_under_rocprof.txt" 2> "$OUT/trace_c2.log"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_gqa" -o gqa -- \
+  python3 tools/bench_gqa.py > "$OUT/gqa_under_rocprof.txt" 2> "$OUT/trace_gqa.log"
 MLA_TARGETS=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_mla" -o mla -- \
   python3 tools/bench_mla.py 256 16 4096 > "$OUT/mla_under_rocprof.txt" 2> "$OUT/trace_mla.log"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_prefill" -o prefill -- \
@@ -37,10 +41,15 @@ timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_
 step secondary benchmarks
 {
   timeout -k 10 200 python3 tools/bench_misc.py
+  timeout -k 10 200 python3 tools/bench_sampler.py
+  timeout -k 10 200 python3 tools/bench_sampler.py 256 128256
   timeout -k 10 200 python3 tools/bench_gqa.py
+  timeout -k 10 200 python3 tools/bench_locality.py
+  timeout -k 10 200 python3 tools/tune_decode.py c2 256
   for a in "64 16 4096" "256 16 4096" "128 16 8192"; do MLA_TARGETS=0,0 timeout -k 10 120 python3 tools/bench_mla.py $a | tail -1; done
   for a in "16 2048 8 8 64" "4 8192 8 8 64" "8 4096 16 2 128"; do timeout -k 10 120 python3 tools/bench_prefill.py $a; done
   timeout -k 10 200 python3 tools/bench_engine.py 256 512 32
   timeout -k 10 200 python3 tools/bench_engine.py 128 256 64
+  timeout -k 10 200 python3 tools/bench_engine.py 8 4096 8 1024
 } > "$OUT/secondary.txt" 2> "$OUT/secondary.err"
 find "$OUT" -name '*.csv' | head -40 >&2

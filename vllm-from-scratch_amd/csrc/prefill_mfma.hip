@@ -81,11 +81,12 @@ template <class Tag, int D>
 __global__ void __launch_bounds__(kWaves * kWave, 2) prefill_mfma_kernel(const PrefillParams p) {
   constexpr int KS = D / 16;          // k-steps of the S^T product (over head_dim)
   constexpr int DT = D / 32;          // 32-row tiles of O^T (over head_dim)
-  constexpr int ROWB = D * 2;         // bytes per K / V row in LDS
+  constexpr int ROWB = D * 2;         // bytes per K row in LDS (chunks XOR-swizzled)
+  constexpr int ROWBV = D * 2 + 16;   // V row pitch: 16 B of padding keeps the four rows of a transposing read on distinct banks
   constexpr int CPR = D / 8;          // 16-byte chunks per row
   constexpr int LOADS = kKT * CPR / (kWaves * kWave);  // 16-byte chunks per thread per tile (K, and again V)
   __shared__ __attribute__((aligned(16))) unsigned char sK2[2][kKT * ROWB];   // double-buffered tiles:
-  __shared__ __attribute__((aligned(16))) unsigned char sV2[2][kKT * ROWB];   // one barrier per tile
+  __shared__ __attribute__((aligned(16))) unsigned char sV2[2][kKT * ROWBV];  // one barrier per tile
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 31, h = lane >> 5;
@@ -143,7 +144,7 @@ __global__ void __launch_bounds__(kWaves * kWave, 2) prefill_mfma_kernel(const P
       const int ch = tid + i * (kWaves * kWave);
       const int key = ch / CPR, dc = ch % CPR;
       *reinterpret_cast<u32x4*>(sK + key * ROWB + ((dc ^ (key & 7)) << 4)) = kreg[i];   // XOR-swizzled chunks
-      *reinterpret_cast<u32x4*>(sV + key * ROWB + (dc << 4)) = vreg[i];
+      *reinterpret_cast<u32x4*>(sV + key * ROWBV + (dc << 4)) = vreg[i];
     }
   };
 
@@ -224,11 +225,11 @@ __global__ void __launch_bounds__(kWaves * kWave, 2) prefill_mfma_kernel(const P
         // it receives column (lane&15) of the 4 rows = V[base+0..3][d0 + (lane&15)].
         const int d0 = 32 * dt + 16 * grp;
         const int key_lo = 16 * s4 + 4 * h + qi;
-        const unsigned char* a0 = sV + key_lo * ROWB + (d0 + 4 * pi) * 2;
+        const unsigned char* a0 = sV + key_lo * ROWBV + (d0 + 4 * pi) * 2;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
             (__attribute__((address_space(3))) s16x4*)(a0));
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(a0 + 8 * ROWB));
+            (__attribute__((address_space(3))) s16x4*)(a0 + 8 * ROWBV));
         const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
         const u32x4 va = {lo2[0], lo2[1], hi2[0], hi2[1]};
         o[dt] = Mma<Tag>::run(va, pb, o[dt]);
