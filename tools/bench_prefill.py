@@ -1,5 +1,5 @@
 """Time mi355_prefill_causal (matrix-core kernel vs the VALU causal-mode kernel).
-Usage: python tools/bench_prefill.py [nseq seqlen Hq Hkv D]"""
+Usage: python tools/bench_prefill.py [nseq seqlen Hq Hkv D]   (BENCH_MFMA_ONLY=1 skips the VALU kernel)"""
 import os
 import sys
 
@@ -18,7 +18,7 @@ v = torch.randn((T, Hkv, D), generator=g, device=dev).to(torch.bfloat16)
 cu = torch.arange(0, T + 1, L, dtype=torch.int32, device=dev)
 flops = 4.0 * nseq * Hq * D * (L * (L + 1) / 2)          # QK^T + PV over the causal triangle
 
-for name, env in (('mfma', None), ('valu', '1')):
+for name, env in (('mfma', None), ('valu', '1'))[:1 if os.environ.get('BENCH_MFMA_ONLY') else 2]:
     if env:
         os.environ['MI355_PREFILL_VALU'] = env
     else:

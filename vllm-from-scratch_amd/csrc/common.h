@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/mi355_paged.h"
 
@@ -18,6 +19,12 @@ constexpr int kWave = 64;
 
 // Records `code` and a printf-style message for mi355_last_error(); returns code.
 int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+// Integer tuning knob from the environment (unset or empty: the default).
+inline int env_int(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return (s && *s) ? atoi(s) : dflt;
+}
 // Returns 0 or records + returns the pending hipError_t of the last launch.
 int check_launch(const char* what);
 

@@ -501,11 +501,6 @@ struct MlaPlan {
   size_t ws_bytes;
 };
 
-int env_int2(const char* name, int dflt) {
-  const char* s = getenv(name);
-  return (s && *s) ? atoi(s) : dflt;
-}
-
 int mla_plan(int rows, int H, int R, int P, int max_context, int dtype, MlaPlan* out) {
   if (rows <= 0 || H <= 0) return fail(MI355_EINVAL, "mla_decode: rows/H (%d,%d)", rows, H);
   if (dtype != MI355_BF16 && dtype != MI355_F16)
@@ -522,7 +517,7 @@ int mla_plan(int rows, int H, int R, int P, int max_context, int dtype, MlaPlan*
   // before tokens are split -- with two tiles of prefetch per workgroup, few long workgroups
   // beat many short ones (measured at 256 rows x 4096 tokens: 187 us unsplit, 193 us with 2
   // splits, 212 us with 4).
-  const int target = env_int2("MI355_MLA_TARGET_WGS", R >= 128 ? 256 : 2048);
+  const int target = env_int("MI355_MLA_TARGET_WGS", R >= 128 ? 256 : 2048);
   int64_t want = ceil_div64(target, base);
   const int64_t most = ctx / 128 > 0 ? ctx / 128 : 1;           // at least 4 steps per workgroup
   if (want > most) want = most;

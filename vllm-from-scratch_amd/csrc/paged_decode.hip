@@ -285,11 +285,6 @@ __global__ void __launch_bounds__(256) paged_decode_merge_kernel(const DecodePar
   }
 }
 
-int env_int(const char* name, int dflt) {
-  const char* s = getenv(name);
-  return (s && *s) ? atoi(s) : dflt;
-}
-
 int elems_per_lane(int dtype) { return dtype == MI355_F32 ? 4 : 8; }
 
 #ifndef MI355_DECODE_U
@@ -623,8 +618,10 @@ extern "C" int mi355_prefill_causal(void* out, const void* q, const void* k, con
   // 16-bit inputs at head_dim 64/128 go to the matrix-core kernel; everything else (fp32,
   // other head dims) runs the VALU decode kernel in causal mode below.
   // MI355_PREFILL_VALU=1 forces the latter (A/B measurements).  The matrix-core kernel takes
-  // the row maximum before scaling, which needs a positive scale.
-  if (prefill_mfma_supported(dtype, D) && scale > 0.f && !env_int("MI355_PREFILL_VALU", 0))
+  // the row maximum before scaling, which needs a positive scale, and addresses a tile's rows
+  // with 32-bit byte offsets, which bounds the token stride.
+  if (prefill_mfma_supported(dtype, D) && scale > 0.f && kv_stride_tok < (1LL << 24) &&
+      !env_int("MI355_PREFILL_VALU", 0))
     return prefill_mfma_launch(out, q, k, v, q_stride_tok, kv_stride_tok, cu_seqlens, nseq, total_tokens,
                                max_seqlen, Hq, Hkv, D, scale, dtype, static_cast<hipStream_t>(stream));
   DecodeParams p;

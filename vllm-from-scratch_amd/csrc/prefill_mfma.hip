@@ -3,8 +3,8 @@
 // The prompt's QK^T and PV products are real dense contractions (Tq x Tk x D per
 // head), so unlike decode they belong on MFMA.  Flash-attention structure:
 //
-//   workgroup = 4 waves = 128 consecutive query rows of one (sequence, query head);
-//   wave      = 32 query rows; K/V are walked in 64-key tiles shared by the 4 waves
+//   workgroup = 4 or 8 waves = 128 or 256 consecutive query rows of one (sequence, query head);
+//   wave      = 32 query rows; K/V are walked in 64-key tiles shared by the waves
 //               through LDS (register-staged: the next tile's global loads are issued
 //               before the current tile is reduced).
 //   S^T = K . Q^T  with v_mfma_f32_32x32x16: the 32x32 result has the QUERY on the lane
@@ -31,8 +31,6 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kQW = 32;              // query rows per wave
-constexpr int kWaves = 4;
-constexpr int kQT = kQW * kWaves;    // query rows per workgroup
 constexpr int kKT = 64;              // keys per tile
 
 struct PrefillParams {
@@ -42,7 +40,7 @@ struct PrefillParams {
   const void* v;
   const int32_t* cu;
   int64_t q_stride_tok, kv_stride_tok;
-  int nseq, n_qt_max, Hq, Hkv, total_tokens;
+  int nseq, n_qt_max, max_seqlen, Hq, Hkv, total_tokens;
   float scale_log2e;
 };
 
@@ -74,20 +72,58 @@ struct Mma<F16> {
   }
 };
 
+// Packed f32 arithmetic (v_pk_fma_f32, v_pk_add_f32, v_pk_mul_f32) issued beside MFMAs stalls the
+// SIMD far longer than the two scalar instructions it replaces, so this kernel is compiled without
+// it: the softmax arithmetic stays single-issue VALU that fits between matrix instructions.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MI355_NO_PACKED_F32 __attribute__((target("no-packed-fp32-ops")))
+#else
+#define MI355_NO_PACKED_F32
+#endif
+
+// The HIP header's __syncthreads / __shfl_xor / __all are ordinary functions compiled with the
+// default feature set and would stay out of line in a kernel compiled without packed f32;
+// these are the same operations on builtins.
+__device__ __forceinline__ void wg_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// Both values of the lane pair (c, c+32), in every lane of the pair: one v_permlane32_swap
+// (it exchanges the upper 32 lanes of its first register with the lower 32 of its second).
+// Written as asm because this compiler's builtin returns the first result for both; the s_nop
+// covers the wait states the instruction needs after a VALU write of its operands.
+__device__ __forceinline__ void pair_values(float x, float& lo, float& hi) {
+  float a = x, b = x;
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  lo = a;
+  hi = b;
+}
+
 // Two workgroups (8 waves) per CU: with a 256-register budget the 64 accumulator registers of a
 // wave stay in VGPRs, where the softmax arithmetic reads and writes them directly (a tighter
 // budget parks them in AccVGPRs and pays a copy per register per use).
-template <class Tag, int D>
-__global__ void __launch_bounds__(kWaves * kWave, 2) prefill_mfma_kernel(const PrefillParams p) {
+#ifndef MI355_PF_OCC64
+#define MI355_PF_OCC64 3
+#endif
+template <class Tag, int D, int kWaves>
+__global__ void __launch_bounds__(kWaves * kWave, (D == 64 && kWaves == 4) ? MI355_PF_OCC64 : 2) MI355_NO_PACKED_F32 prefill_mfma_kernel(const PrefillParams p) {
+  constexpr int kQT = kQW * kWaves;   // query rows per workgroup
   constexpr int KS = D / 16;          // k-steps of the S^T product (over head_dim)
   constexpr int DT = D / 32;          // 32-row tiles of O^T (over head_dim)
   constexpr int ROWB = D * 2;         // bytes per K row in LDS (chunks XOR-swizzled)
-  constexpr int ROWBV = D * 2 + 16;   // V row pitch: 16 B of padding keeps the four rows of a transposing read on distinct banks
+  // LDS banking (64 banks of 4 B).  A 16-byte read is served 16 lanes at a time, and those 16 lanes
+  // hold keys c with 16 different values of c mod 16; XOR-ing the chunk index with the key's index
+  // within a 256-byte span of rows puts them on 16 different 4-bank groups.  A transposing 8-byte
+  // read is served 32 lanes at a time = 4 rows x (2 x 4) column pieces of 2 banks; a row pitch of
+  // 48 or 80 banks (= +/-16 mod 64) makes the four rows tile all 64 banks.
+  constexpr int ROWBV = D * 2 + 64;   // V row pitch
   constexpr int CPR = D / 8;          // 16-byte chunks per row
   constexpr int LOADS = kKT * CPR / (kWaves * kWave);  // 16-byte chunks per thread per tile (K, and again V)
   __shared__ __attribute__((aligned(16))) unsigned char sK2[2][kKT * ROWB];   // double-buffered tiles:
   __shared__ __attribute__((aligned(16))) unsigned char sV2[2][kKT * ROWBV];  // one barrier per tile
 
+  auto kswz = [](int key) __attribute__((always_inline)) { return (key / (256 / ROWB)) & (CPR - 1); };
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 31, h = lane >> 5;
   int bid = blockIdx.x;
@@ -124,26 +160,46 @@ __global__ void __launch_bounds__(kWaves * kWave, 2) prefill_mfma_kernel(const P
   const char* kbase = static_cast<const char*>(p.k);
   const char* vbase = static_cast<const char*>(p.v);
 
+  // A thread always stages the same (key, chunk) positions of a tile, so a load address is a
+  // wave-uniform tile base plus a per-thread 32-bit offset that only changes in the sequence's
+  // last, partial tile (rows past the end re-read the last row; they are masked below).
   u32x4 kreg[LOADS], vreg[LOADS];
-  auto issue_loads = [&](int tile) {
+  const uint32_t rowbytes = (uint32_t)p.kv_stride_tok * 2u;
+  uint32_t voff[LOADS];
 #pragma unroll
-    for (int i = 0; i < LOADS; ++i) {
-      const int ch = tid + i * (kWaves * kWave);
-      const int key = ch / CPR, dc = ch % CPR;
-      const int row = seq_start + min(tile * kKT + key, len - 1);   // rows past the end are masked below
-      const int64_t off = ((int64_t)row * p.kv_stride_tok + (int64_t)kvh * D + dc * 8) * 2;
-      kreg[i] = *reinterpret_cast<const u32x4*>(kbase + off);
-      vreg[i] = *reinterpret_cast<const u32x4*>(vbase + off);
+  for (int i = 0; i < LOADS; ++i) {
+    const int ch = tid + i * (kWaves * kWave);
+    voff[i] = (uint32_t)(ch / CPR) * rowbytes + (uint32_t)(kvh * D + (ch % CPR) * 8) * 2u;
+  }
+  auto issue_loads = [&](int tile) __attribute__((always_inline)) {
+    const int64_t base = (int64_t)(seq_start + tile * kKT) * rowbytes;
+    const char* kb = kbase + base;
+    const char* vb = vbase + base;
+    const int last = len - 1 - tile * kKT;                          // tile-relative index of the last valid row
+    if (last >= kKT - 1) {
+#pragma unroll
+      for (int i = 0; i < LOADS; ++i) {
+        kreg[i] = *reinterpret_cast<const u32x4*>(kb + voff[i]);
+        vreg[i] = *reinterpret_cast<const u32x4*>(vb + voff[i]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < LOADS; ++i) {
+        const int ch = tid + i * (kWaves * kWave);
+        const uint32_t off = (uint32_t)min(ch / CPR, last) * rowbytes + (uint32_t)(kvh * D + (ch % CPR) * 8) * 2u;
+        kreg[i] = *reinterpret_cast<const u32x4*>(kb + off);
+        vreg[i] = *reinterpret_cast<const u32x4*>(vb + off);
+      }
     }
   };
-  auto write_lds = [&](int buf) {
+  auto write_lds = [&](int buf) __attribute__((always_inline)) {
     unsigned char* sK = sK2[buf];
     unsigned char* sV = sV2[buf];
 #pragma unroll
     for (int i = 0; i < LOADS; ++i) {
       const int ch = tid + i * (kWaves * kWave);
       const int key = ch / CPR, dc = ch % CPR;
-      *reinterpret_cast<u32x4*>(sK + key * ROWB + ((dc ^ (key & 7)) << 4)) = kreg[i];   // XOR-swizzled chunks
+      *reinterpret_cast<u32x4*>(sK + key * ROWB + ((dc ^ kswz(key)) << 4)) = kreg[i];   // XOR-swizzled chunks
       *reinterpret_cast<u32x4*>(sV + key * ROWBV + (dc << 4)) = vreg[i];
     }
   };
@@ -154,7 +210,7 @@ __global__ void __launch_bounds__(kWaves * kWave, 2) prefill_mfma_kernel(const P
   issue_loads(0);
   write_lds(0);
   if (ntiles > 1) issue_loads(1);
-  __syncthreads();
+  wg_barrier();
   for (int t = 0; t < ntiles; ++t) {
     const unsigned char* sK = sK2[t & 1];
     const unsigned char* sV = sV2[t & 1];
@@ -168,7 +224,7 @@ __global__ void __launch_bounds__(kWaves * kWave, 2) prefill_mfma_kernel(const P
       const int row = 32 * kt + c;
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        const u32x4 a = *reinterpret_cast<const u32x4*>(sK + row * ROWB + (((2 * s + h) ^ (row & 7)) << 4));
+        const u32x4 a = *reinterpret_cast<const u32x4*>(sK + row * ROWB + (((2 * s + h) ^ kswz(row)) << 4));
         st[kt] = Mma<Tag>::run(a, qf[s], s == 0 ? f32x16(0.f) : st[kt]);   // first step accumulates onto the constant 0
       }
     }
@@ -187,7 +243,11 @@ __global__ void __launch_bounds__(kWaves * kWave, 2) prefill_mfma_kernel(const P
     float mx = fmaxf(st[0][0], st[1][0]);
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = __builtin_fmaxf(__builtin_fmaxf(mx, st[0][r]), st[1][r]);   // v_max3_f32
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    {
+      float a, b;
+      pair_values(mx, a, b);
+      mx = __builtin_fmaxf(a, b);
+    }
     const float m_new = fmaxf(m_run, mx * p.scale_log2e);
     const float f = fast_exp2(m_run - m_new);
     m_run = m_new;
@@ -202,9 +262,13 @@ __global__ void __launch_bounds__(kWaves * kWave, 2) prefill_mfma_kernel(const P
     float psum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) psum += psum16[r];
-    psum += __shfl_xor(psum, 32);
+    {
+      float a, b;
+      pair_values(psum, a, b);
+      psum = a + b;
+    }
     l_run = l_run * f + psum;
-    if (!__all(f == 1.0f)) {                         // the running maximum moved for some query of the wave
+    if (__builtin_amdgcn_ballot_w64(f != 1.0f) != 0) {                         // the running maximum moved for some query of the wave
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) o[dt] *= f;
     }
@@ -240,7 +304,7 @@ __global__ void __launch_bounds__(kWaves * kWave, 2) prefill_mfma_kernel(const P
       write_lds((t + 1) & 1);
       if (t + 2 < ntiles) issue_loads(t + 2);
     }
-    __syncthreads();
+    wg_barrier();
   }
 
   // ---- normalise and store: lane (c,h) holds O[my_q][32*dt + 8*(r>>2) + 4*h + (r&3)]
@@ -260,11 +324,23 @@ __global__ void __launch_bounds__(kWaves * kWave, 2) prefill_mfma_kernel(const P
   }
 }
 
+template <class Tag, int D, int kWaves>
+int launch_w(PrefillParams p, hipStream_t s) {
+  p.n_qt_max = (p.max_seqlen + kQW * kWaves - 1) / (kQW * kWaves);
+  const int64_t grid = (int64_t)p.nseq * p.n_qt_max * p.Hq;
+  hipLaunchKernelGGL((prefill_mfma_kernel<Tag, D, kWaves>), dim3((unsigned)grid), dim3(kWaves * kWave), 0, s, p);
+  return check_launch("prefill_mfma_kernel");
+}
+
+// 256-row workgroups stage every K/V tile once for twice the queries (half the LDS writes and
+// global loads per product), but their waves idle more on the diagonal and there are half as
+// many of them: they take over once the launch still fills the chip several times.
 template <class Tag, int D>
 int launch(const PrefillParams& p, hipStream_t s) {
-  const int64_t grid = (int64_t)p.nseq * p.n_qt_max * p.Hq;
-  hipLaunchKernelGGL((prefill_mfma_kernel<Tag, D>), dim3((unsigned)grid), dim3(kWaves * kWave), 0, s, p);
-  return check_launch("prefill_mfma_kernel");
+  static const int force = env_int("MI355_PREFILL_WAVES", 0);
+  const int64_t wgs8 = (int64_t)p.nseq * ((p.max_seqlen + 8 * kQW - 1) / (8 * kQW)) * p.Hq;
+  const bool big = force ? force == 8 : (p.max_seqlen >= 4096 && wgs8 >= 2 * 256);
+  return big ? launch_w<Tag, D, 8>(p, s) : launch_w<Tag, D, 4>(p, s);
 }
 
 }  // namespace
@@ -286,7 +362,7 @@ int prefill_mfma_launch(void* out, const void* q, const void* k, const void* v, 
   p.q_stride_tok = q_stride_tok;
   p.kv_stride_tok = kv_stride_tok;
   p.nseq = nseq;
-  p.n_qt_max = (max_seqlen + kQT - 1) / kQT;
+  p.max_seqlen = max_seqlen;
   p.Hq = Hq;
   p.Hkv = Hkv;
   p.total_tokens = total_tokens;
