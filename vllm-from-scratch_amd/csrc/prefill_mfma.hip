@@ -103,11 +103,8 @@ __device__ __forceinline__ void pair_values(float x, float& lo, float& hi) {
 // Two workgroups (8 waves) per CU: with a 256-register budget the 64 accumulator registers of a
 // wave stay in VGPRs, where the softmax arithmetic reads and writes them directly (a tighter
 // budget parks them in AccVGPRs and pays a copy per register per use).
-#ifndef MI355_PF_OCC64
-#define MI355_PF_OCC64 3
-#endif
 template <class Tag, int D, int kWaves>
-__global__ void __launch_bounds__(kWaves * kWave, (D == 64 && kWaves == 4) ? MI355_PF_OCC64 : 2) MI355_NO_PACKED_F32 prefill_mfma_kernel(const PrefillParams p) {
+__global__ void __launch_bounds__(kWaves * kWave, 2) MI355_NO_PACKED_F32 prefill_mfma_kernel(const PrefillParams p) {
   constexpr int kQT = kQW * kWaves;   // query rows per workgroup
   constexpr int KS = D / 16;          // k-steps of the S^T product (over head_dim)
   constexpr int DT = D / 32;          // 32-row tiles of O^T (over head_dim)
