@@ -13,8 +13,11 @@ One step = one decode step of one attention layer for the whole batch:
   (2) paged decode attention over the 2048-token context (mi355_paged_decode)
   (3) greedy sampling from fp32 logits [256, 32000]      (mi355_sample_argmax)
   (4) with N > 1: all-gather of the sampled ids across ranks (RCCL), asynchronous: ranks do
-      not need each other's ids to go on decoding, so step i's collective overlaps step i+1;
-      every collective has completed before the timed region closes
+      not need each other's ids to go on decoding, so a collective overlaps the steps after it.
+      The ids of --gather-every consecutive steps (default 4) travel in one collective: its
+      fixed cost (about 26 us per call measured on a one-rank communicator, mostly the two
+      stream dependencies around it) would otherwise be a seventh of a 182 us step.  Every id
+      is exchanged, and every collective has completed, before the timed region closes
 `value` = sequences (= tokens) decoded per second over all ranks.  `roofline`
 prices step (2), the dominant kernel, against HBM bandwidth using the
 algorithmic byte count; `cpu_baseline` times the reference-shaped CPU decode
@@ -114,6 +117,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--config', default='metric', choices=sorted(CONFIGS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--gather-every', type=int, default=4,
+                    help='steps whose sampled ids share one all-gather (N > 1); every id is exchanged inside the timed region')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -130,7 +135,10 @@ def main():
     device = torch.device('cuda', local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
     import torch.distributed as dist
-    if world > 1:
+    # BENCH_FORCE_DIST=1 under a one-process torch.distributed.run: the process group, barrier,
+    # asynchronous all-gather and max-reduce run on a one-rank RCCL communicator
+    use_dist = world > 1 or bool(os.environ.get('BENCH_FORCE_DIST'))
+    if use_dist:
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=device)
         else:
@@ -149,7 +157,7 @@ def main():
     inp = build_inputs(cfg, device, seed=rank, sets=2 if args.config == 'metric' else 4)
     nsets = len(inp['pools'])
     out = torch.empty((B, H, D), dtype=torch.bfloat16, device=device)
-    gather = dp.OverlappedTokenGather(B, device)
+    gather = dp.OverlappedTokenGather(B, device, single_rank_collective=use_dist, every=args.gather_every)
 
     ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -166,7 +174,7 @@ def main():
         gather.launch(i)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -183,7 +191,7 @@ def main():
     gather.drain()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -207,7 +215,7 @@ def main():
             "config": {"workload": f"paged decode step: batch={B}/GPU, ctx={S}, heads={H}, head_dim={D}, "
                                    f"block_size={BS}, bf16 KV [blocks,heads,{BS},{D}], scattered block table; "
                                    f"kv-write + paged attention + greedy argmax(vocab={cfg['vocab']})"
-                                   + (" + RCCL all-gather of ids" if world > 1 else ""),
+                                   + (f" + RCCL all-gather of ids (one collective per {args.gather_every} steps)" if use_dist else ""),
                        "batch_per_gpu": B, "context": S, "block_size": BS, "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
@@ -229,7 +237,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, inp)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -51,33 +51,36 @@ def test_all_gather_world2_matches_single_process(tmp_path, total):
         assert torch.equal(torch.load(tmp_path / f'r{r}.pt'), want)
 
 
-def _overlap_worker(rank, world, port, out_dir):
+def _overlap_worker(rank, world, port, out_dir, every=1):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        n, steps = 5, 7
-        g = dp.OverlappedTokenGather(n, 'cpu')
+        n, steps = 5, 7 if every == 1 else 23
+        g = dp.OverlappedTokenGather(n, 'cpu', every=every)
         seen = []
         for i in range(steps):
             buf = g.send_buffer(i)
             buf.copy_(torch.arange(n, dtype=torch.int32) + 100 * rank + 1000 * i)   # this step's "sampled ids"
             g.launch(i)
-            if i >= 1:
-                seen.append(g.result(i - 1).clone())        # the previous step's ids, one step late
-        seen.append(g.result(steps - 1).clone())
+            if i >= every:
+                seen.append(g.result(i - every).clone())    # an exchanged group's ids, `every` steps late
+        g.flush()                                            # the last group may be partly filled
+        for i in range(steps - every, steps):
+            seen.append(g.result(i).clone())
         g.drain()
         torch.save(torch.stack(seen), os.path.join(out_dir, f'o{rank}.pt'))
     finally:
         dist.destroy_process_group()
 
 
-def test_overlapped_gather_world2_returns_every_step_in_rank_order(tmp_path):
+@pytest.mark.parametrize('every', [1, 4])
+def test_overlapped_gather_world2_returns_every_step_in_rank_order(tmp_path, every):
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
-    mp.spawn(_overlap_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_overlap_worker, args=(2, port, str(tmp_path), every), nprocs=2, join=True)
     want = torch.stack([torch.cat([torch.arange(5, dtype=torch.int32) + 100 * r + 1000 * i for r in range(2)])
-                        for i in range(7)])
+                        for i in range(7 if every == 1 else 23)])
     for r in range(2):
         assert torch.equal(torch.load(tmp_path / f'o{r}.pt'), want)
 
@@ -87,4 +90,17 @@ def test_overlapped_gather_single_process_passthrough():
     g.send_buffer(0).copy_(torch.tensor([4, 5, 6], dtype=torch.int32))
     g.launch(0)
     assert g.result(0).tolist() == [4, 5, 6]
+    g.drain()
+
+
+def test_overlapped_gather_batched_single_process():
+    g = dp.OverlappedTokenGather(2, 'cpu', every=3)
+    for i in range(4):
+        g.send_buffer(i).copy_(torch.tensor([10 * i, 10 * i + 1], dtype=torch.int32))
+        g.launch(i)
+    assert g.result(1).tolist() == [10, 11]
+    with pytest.raises(RuntimeError, match='not been exchanged'):
+        g.result(3)
+    g.flush()
+    assert g.result(3).tolist() == [30, 31]
     g.drain()

@@ -67,32 +67,68 @@ class OverlappedTokenGather:
     """All-gather of every step's sampled ids that does not stall the step after it.
 
     Ranks never need each other's ids to continue decoding (the gathered vector feeds the
-    front end), so step i's collective may still be in flight while step i + 1 computes.  Two
-    send / receive buffer pairs alternate: `send_buffer(i)` is where step i's sampler writes
-    (first waiting, on the stream, for the collective of step i - 2 that used the same pair),
+    front end), so step i's collective may still be in flight while later steps compute.
+    `SLOTS` send / receive buffer pairs rotate: `send_buffer(i)` is where step i's sampler writes,
     `launch(i)` starts the asynchronous all-gather, `result(i)` / `drain()` wait for it.
-    With the nccl (= RCCL) backend waiting is a stream dependency, not a host block.
+    Before a pair is reused, the collective of step i - SLOTS that used it must be over: that is
+    first checked from the host (an event query, no GPU work); only if it is still running does
+    the compute stream wait for it.  On this hardware a wait between two streams costs the
+    waiting stream several microseconds even when it is already satisfied, so the compute stream
+    takes none in the steady state.  With the nccl (= RCCL) backend waiting is a stream
+    dependency, not a host block.
     Equal shard sizes only (pad the local batch otherwise).  Without a process group, or on a
-    single rank, the local ids are the result.
+    single rank, the local ids are the result; `single_rank_collective=True` issues the
+    collective on a one-rank group too (a rehearsal of the RCCL path on a one-GPU machine).
     """
 
-    def __init__(self, n_local: int, device, dtype=torch.int32, group=None):
+    SLOTS = 4
+
+    def __init__(self, n_local: int, device, dtype=torch.int32, group=None, single_rank_collective=False,
+                 every: int = 1):
+        """`every` > 1 batches the exchange: the ids of `every` consecutive steps travel in one
+        collective, issued after the last of them (or by `flush()` / `drain()`), so its fixed cost
+        (a host call, a kernel and two stream dependencies) is paid once per group of steps."""
+        if every < 1:
+            raise ValueError(f"every must be >= 1, got {every}")
         self.group = group
-        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.n_local, self.every = n_local, every
+        self.active = dist.is_available() and dist.is_initialized() and (
+            dist.get_world_size(group) > 1 or single_rank_collective)
         self.world = dist.get_world_size(group) if self.active else 1
         # gloo cannot move device memory: stage through the host, synchronously (CPU tests, rehearsals)
         self.host_staged = self.active and dist.get_backend(group) == 'gloo' and torch.device(device).type == 'cuda'
-        self.send = [torch.zeros((n_local,), dtype=dtype, device=device) for _ in range(2)]
-        self.recv = [torch.zeros((n_local * self.world,), dtype=dtype, device=device) if self.active else None
-                     for _ in range(2)]
-        self.work = [None, None]
+        self.send = [torch.zeros((every * n_local,), dtype=dtype, device=device) for _ in range(self.SLOTS)]
+        self.recv = [torch.zeros((self.world * every * n_local,), dtype=dtype, device=device) if self.active
+                     else None for _ in range(self.SLOTS)]
+        self.work = [None] * self.SLOTS
+        self.pending = [False] * self.SLOTS      # written by send_buffer users, not yet exchanged
+
+    def _slot(self, step: int) -> int:
+        return (step // self.every) % self.SLOTS
 
     def send_buffer(self, step: int) -> torch.Tensor:
-        self._wait(step & 1)
-        return self.send[step & 1]
+        slot, j = self._slot(step), step % self.every
+        if j == 0 or not self.pending[slot]:
+            work = self.work[slot]
+            if work is not None and work.is_completed():
+                self.work[slot] = None
+            self._wait(slot)
+        self.pending[slot] = True
+        return self.send[slot][j * self.n_local:(j + 1) * self.n_local]
 
     def launch(self, step: int) -> None:
-        slot = step & 1
+        """Step `step`'s ids are in its send buffer; exchanges the group when this was its last step."""
+        if step % self.every == self.every - 1:
+            self._exchange(self._slot(step))
+
+    def flush(self) -> None:
+        """Exchanges a group that is only partly filled (the end of a run)."""
+        for slot in range(self.SLOTS):
+            if self.pending[slot]:
+                self._exchange(slot)
+
+    def _exchange(self, slot: int) -> None:
+        self.pending[slot] = False
         if not self.active:
             return
         if self.host_staged:
@@ -109,11 +145,20 @@ class OverlappedTokenGather:
             self.work[slot] = None
 
     def result(self, step: int) -> torch.Tensor:
-        """Gathered ids of `step` (valid until send_buffer(step + 2) is requested)."""
-        slot = step & 1
+        """Gathered ids of `step`, in rank order (valid until its buffers come round again,
+        SLOTS * every steps later).  Its group must have been exchanged (`launch` of the group's
+        last step, or `flush`)."""
+        slot, j = self._slot(step), step % self.every
+        if self.pending[slot]:
+            raise RuntimeError(f"step {step}: its group of {self.every} steps has not been exchanged yet (flush())")
         self._wait(slot)
-        return self.recv[slot] if self.active else self.send[slot]
+        if not self.active:
+            return self.send[slot][j * self.n_local:(j + 1) * self.n_local]
+        if self.every == 1:
+            return self.recv[slot]
+        return self.recv[slot].view(self.world, self.every, self.n_local)[:, j, :].reshape(-1)
 
     def drain(self) -> None:
-        self._wait(0)
-        self._wait(1)
+        self.flush()
+        for slot in range(self.SLOTS):
+            self._wait(slot)
