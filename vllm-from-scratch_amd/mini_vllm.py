@@ -711,12 +711,30 @@ class FFN(nn.Module):
         self.gate = nn.Linear(hidden_size, intermediate_size, bias=False)
         self.up = nn.Linear(hidden_size, intermediate_size, bias=False)
         self.down = nn.Linear(intermediate_size, hidden_size, bias=False)
+        self._gate_up, self._gate_up_version = None, None
+
+    def _gate_up_weight(self) -> torch.Tensor:
+        """[gate.weight; up.weight] as one matrix, rebuilt when either parameter was replaced or
+        written in place (`weights_version`), so that the two projections are one GEMM."""
+        version = self.weights_version()
+        if self._gate_up_version != version:
+            self._gate_up = torch.cat([self.gate.weight.detach(), self.up.weight.detach()], dim=0)
+            self._gate_up_version = version
+        return self._gate_up
+
+    def weights_version(self) -> tuple:
+        g, u = self.gate.weight, self.up.weight
+        return (g.data_ptr(), u.data_ptr(), g._version, u._version, g.dtype)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        gate, up = self.gate(x), self.up(x)
-        if _kernel_rows(gate) and _kernel_rows(up):
-            return self.down(ops.silu_mul(gate, up))
-        return self.down(F.silu(gate) * up)
+        if _kernel_rows(x, self.gate.weight, self.up.weight):
+            both = F.linear(x, self._gate_up_weight())
+            inter = self.gate.weight.shape[0]
+            gate, up = both[:, :inter], both[:, inter:]
+            if _kernel_rows(gate) and _kernel_rows(up):
+                return self.down(ops.silu_mul(gate, up))
+            return self.down(F.silu(gate) * up)
+        return self.down(F.silu(self.gate(x)) * self.up(x))
 
 
 class TransformerLayer(nn.Module):
@@ -731,6 +749,18 @@ class TransformerLayer(nn.Module):
         attn = self.attn(self.norm1(x), positions, kv_cache, slot_mapping, seq_lens, is_prefill, plan)
         x, normed = self.norm2.add_forward(x, attn)
         return x + self.ffn(normed)
+
+    def forward_carry(self, x, delta, positions, kv_cache, slot_mapping, seq_lens, is_prefill, plan):
+        """The same layer on a residual stream given as x + delta (delta None: just x), returning
+        (stream before the feed-forward output, feed-forward output): the last addition is left to
+        the next normalisation, which fuses it."""
+        if delta is None:
+            normed = self.norm1(x)
+        else:
+            x, normed = self.norm1.add_forward(x, delta)
+        attn = self.attn(normed, positions, kv_cache, slot_mapping, seq_lens, is_prefill, plan)
+        x, normed = self.norm2.add_forward(x, attn)
+        return x, self.ffn(normed)
 
 
 class MiniTransformer(nn.Module):
@@ -787,12 +817,20 @@ class MiniTransformer(nn.Module):
                         is_prefill: Optional[List[bool]] = None) -> torch.Tensor:
         """The layer stack for an already planned step; `last` = flattened index of each
         request's final token (None: every token is one, as in a pure decode step)."""
-        x = self.embedding(token_ids)
+        x, delta = self.embedding(token_ids), None
         for i, layer in enumerate(self.layers):
-            x = layer(x, positions, (self.k_cache[i], self.v_cache[i]), slot_mapping, seq_lens, is_prefill, plan)
+            x, delta = layer.forward_carry(x, delta, positions, (self.k_cache[i], self.v_cache[i]), slot_mapping,
+                                           seq_lens, is_prefill, plan)
         if last is not None and len(last) != x.shape[0]:
             x = x[last]
-        return self.lm_head(self.norm(x))
+            delta = delta[last] if delta is not None else None
+        if delta is None:
+            return self.lm_head(self.norm(x))
+        return self.lm_head(self.norm.add_forward(x, delta)[1])
+
+    def weights_version(self) -> tuple:
+        """Changes whenever a parameter that a captured step holds a derived copy of does."""
+        return tuple(layer.ffn.weights_version() for layer in self.layers)
 
 
 # ---------------------------------------------------------------------------
@@ -951,11 +989,12 @@ class MiniVLLM:
         rows = -(-nseq // quantum) * quantum
         bound = -(-max_context // 256) * 256
         tables = self._device_tables
-        key = (rows, bound, tables.tables.data_ptr(), tables.tables.shape[1], self.model.k_cache.data_ptr())
+        key = (rows, bound, tables.tables.data_ptr(), tables.tables.shape[1], self.model.k_cache.data_ptr(),
+               self.model.weights_version())
         graph = self._graphs.get(key)
         if graph is None:
             for stale in [k for k in self._graphs if k[2:] != key[2:]]:
-                del self._graphs[stale]          # block tables or KV buffers were reallocated
+                del self._graphs[stale]          # block tables, KV buffers or weights were replaced
             while len(self._graphs) >= self.MAX_GRAPHS:
                 self._graphs.popitem(last=False)
             graph = self._graphs[key] = DecodeStepGraph(self.model, tables, rows, bound)
