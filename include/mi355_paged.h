@@ -248,12 +248,17 @@ int mi355_silu_mul(void* out, const void* gate, int64_t gate_stride, const void*
  *   block_tables[r][:] = table_pool[row][:]                                       (int32, [rows, width])
  *   slots[r] = table_pool[row][position / block_size] * block_size + position % block_size
  * A negative position marks a padding row: context 0 and slot -1 (no cache write).
+ * A negative token entry -1-j stands for prev_ids[j], the id the sampler wrote for row j of the
+ * previous step (the reference appends it on the host, :312-333, before it can schedule the next
+ * step; reading it on the device lets the next step be issued before the host has seen it).
+ * prev_ids is int32 [prev_rows] and may be NULL when prev_rows is 0.
  * table_pool is [pool_rows, width] int32.
  */
 int mi355_decode_step_inputs(int64_t* token_ids, int64_t* positions, int64_t* slots,
                              int32_t* context_lens, int32_t* block_tables, const int32_t* packed,
-                             const int32_t* table_pool, int32_t rows, int32_t pool_rows, int32_t width,
-                             int32_t block_size, void* stream);
+                             const int32_t* table_pool, const int32_t* prev_ids, int32_t prev_rows,
+                             int32_t rows, int32_t pool_rows, int32_t width, int32_t block_size,
+                             void* stream);
 
 /*
  * Attention of several NEW query tokens per sequence over the paged cache, each token attending

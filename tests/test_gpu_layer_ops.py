@@ -136,9 +136,9 @@ def test_layer_ops_reject_bad_arguments(ops, device):
 
 
 # ------------------------------------------------------------------ engine: graph replay == eager
-def _run(mv, graphs, dtype, prompts, max_new, temperature=0.0, seed=0, **kw):
+def _run(mv, graphs, dtype, prompts, max_new, temperature=0.0, seed=0, vocab=300, **kw):
     torch.manual_seed(7)
-    eng = mv.MiniVLLM(vocab_size=300, hidden_size=128, num_layers=2, num_heads=4, intermediate_size=256,
+    eng = mv.MiniVLLM(vocab_size=vocab, hidden_size=128, num_layers=2, num_heads=4, intermediate_size=256,
                       num_kv_blocks=256, block_size=8, max_num_seqs=16, max_num_batched_tokens=256,
                       device='cuda', dtype=dtype, decode_graphs=graphs, **kw)
     for p, n in zip(prompts, max_new):
@@ -173,6 +173,62 @@ def test_engine_graph_decode_equals_eager(device, dtype):
     assert [r.request_id for r in graph.scheduler.finished] == [r.request_id for r in eager.scheduler.finished]
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_engine_lookahead_decode_equals_step_by_step(device, dtype):
+    """The engine that issues the next decode step before reading the current one's tokens emits,
+    per request, exactly the tokens of the step-by-step engines -- over a run in which requests end
+    on the end-of-sequence id (vocabulary of 12: id 0 is sampled often) at steps nobody can predict,
+    others end by length, and the batch shrinks accordingly."""
+    import mini_vllm as mv
+    rng = np.random.default_rng(23)
+    prompts = [[int(t) for t in rng.integers(1, 12, size=int(n))] for n in rng.integers(2, 40, size=16)]
+    max_new = [int(n) for n in rng.integers(3, 60, size=16)]
+    eager, out_e, _ = _run(mv, False, dtype, prompts, max_new, vocab=12)
+    plain, out_p, steps_p = _run(mv, True, dtype, prompts, max_new, vocab=12, decode_lookahead=False)
+    ahead, out_a, steps_a = _run(mv, True, dtype, prompts, max_new, vocab=12, decode_lookahead=True)
+    ended_early = sum(1 for rid, toks in out_e.items() if toks[-1] == 0 and len(toks) < max_new[int(rid.split('-')[1])])
+    assert ended_early >= 3, "the case is meant to exercise end-of-sequence ids"
+    assert out_p == out_e
+    assert out_a == out_e
+    assert steps_a == steps_p
+    assert ahead._inflight is None
+    assert ahead.allocator.num_free == 256
+    assert sorted(r.request_id for r in ahead.scheduler.finished) == sorted(r.request_id for r in eager.scheduler.finished)
+
+
+def test_engine_lookahead_accepts_requests_mid_run(device):
+    """A request added while a speculative step is in flight joins through the general path and
+    every request still gets the tokens it gets when run alone (greedy)."""
+    import mini_vllm as mv
+
+    def build():
+        torch.manual_seed(7)
+        return mv.MiniVLLM(vocab_size=300, hidden_size=128, num_layers=2, num_heads=4, intermediate_size=256,
+                           num_kv_blocks=256, block_size=8, max_num_seqs=16, max_num_batched_tokens=256,
+                           device='cuda', dtype=torch.float32)
+    first, late = [5, 6, 7, 8, 9], [11, 12, 13]
+    eng = build()
+    a = eng.add_request(first, max_new_tokens=20, temperature=0.0)
+    outs = {}
+    for _ in range(6):
+        for rid, tok in eng.step():
+            outs.setdefault(rid, []).append(tok)
+    assert eng._inflight is not None
+    b = eng.add_request(late, max_new_tokens=9, temperature=0.0)
+    while eng.scheduler.has_unfinished:
+        for rid, tok in eng.step():
+            outs.setdefault(rid, []).append(tok)
+    def alone(prompt, n):
+        solo = build()
+        solo.add_request(prompt, max_new_tokens=n, temperature=0.0)
+        toks = []
+        while solo.scheduler.has_unfinished:
+            toks += [tok for _, tok in solo.step()]
+        return toks
+    assert outs[a] == alone(first, 20)
+    assert outs[b] == alone(late, 9)
+
+
 def test_engine_graph_decode_stochastic_rows_repeat(device):
     """Sampling after a replayed step draws from the seeded generator like the eager path."""
     import mini_vllm as mv
@@ -200,6 +256,15 @@ def test_decode_step_inputs_bit_exact(ops, device):
     assert bt.cpu().numpy().tolist() == pool[row].tolist()
     want = [-1 if q < 0 else int(pool[r][q // BS]) * BS + q % BS for q, r in zip(pos.tolist(), row.tolist())]
     assert s.tolist() == want
+    # token entries -1-j are taken from the previous step's id vector on the device
+    prev = torch.from_numpy(rng.integers(0, 32000, size=rows + 5).astype(np.int32)).to(device)
+    refs = tok.copy()
+    refs[::3] = -1 - rng.integers(0, rows + 5, size=len(refs[::3])).astype(np.int32)
+    packed_refs = torch.from_numpy(np.stack([refs, pos, row])).to(device)
+    t2, p2, s2, c2, bt2 = ops.decode_step_inputs(packed_refs, torch.from_numpy(pool).to(device), BS, prev_ids=prev)
+    prev_host = prev.cpu().numpy()
+    assert t2.tolist() == [int(prev_host[-1 - x]) if x < 0 else int(x) for x in refs.tolist()]
+    assert s2.tolist() == want and c2.tolist() == c.tolist()
     # a block size that is not a power of two; a position past the table's last block gets no slot
     t, p, s, c, bt = ops.decode_step_inputs(packed, torch.from_numpy(pool).to(device), 12)
     assert s.tolist() == [-1 if q < 0 or q // 12 >= width else int(pool[r][q // 12]) * 12 + q % 12

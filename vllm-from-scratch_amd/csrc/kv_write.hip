@@ -57,10 +57,12 @@ slot_mapping_kernel(int64_t* out, const int32_t* bt, const int32_t* starts, cons
 // Per-step inputs of a pure decode batch, derived on the device from the three vectors the
 // host uploads (last token, position, block-table row of every sequence).  Thread (r, c)
 // copies entry c of sequence r's block table; thread (r, 0) also writes the scalars.
+// A negative token entry -1-j means "the id the previous step sampled for its row j"
+// (prev_ids[j]): the step can then be issued before the host has seen that id.
 __global__ void __launch_bounds__(256)
 decode_inputs_kernel(int64_t* tok_out, int64_t* pos_out, int64_t* slot_out, int32_t* ctx_out, int32_t* bt_out,
-                     const int32_t* packed, const int32_t* tables, int rows, int table_rows, int width,
-                     int block_size, int bs_shift) {
+                     const int32_t* packed, const int32_t* tables, const int32_t* prev_ids, int prev_rows,
+                     int rows, int table_rows, int width, int block_size, int bs_shift) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)rows * width) return;
   const int r = (int)(idx / width), c = (int)(idx - (int64_t)r * width);
@@ -70,7 +72,12 @@ decode_inputs_kernel(int64_t* tok_out, int64_t* pos_out, int64_t* slot_out, int3
   const int32_t* row = tables + (int64_t)src * width;
   bt_out[idx] = row[c];
   if (c != 0) return;
-  tok_out[r] = packed[r];
+  int tok = packed[r];
+  if (tok < 0) {
+    const int j = -1 - tok;
+    tok = (prev_ids && j < prev_rows) ? prev_ids[j] : 0;
+  }
+  tok_out[r] = tok;
   pos_out[r] = pos < 0 ? 0 : pos;
   ctx_out[r] = pos < 0 ? 0 : pos + 1;
   int64_t slot = -1;  // padding row (position < 0): no cache write, empty context
@@ -88,17 +95,19 @@ using namespace mi355;
 
 extern "C" int mi355_decode_step_inputs(int64_t* token_ids, int64_t* positions, int64_t* slots,
                                         int32_t* context_lens, int32_t* block_tables, const int32_t* packed,
-                                        const int32_t* table_pool, int32_t rows, int32_t pool_rows,
+                                        const int32_t* table_pool, const int32_t* prev_ids,
+                                        int32_t prev_rows, int32_t rows, int32_t pool_rows,
                                         int32_t width, int32_t block_size, void* stream) {
   if (rows == 0) return 0;
   if (!token_ids || !positions || !slots || !context_lens || !block_tables || !packed || !table_pool)
     return fail(MI355_EINVAL, "decode_step_inputs: null pointer");
-  if (rows < 0 || pool_rows <= 0 || width <= 0 || block_size <= 0)
+  if (rows < 0 || pool_rows <= 0 || width <= 0 || block_size <= 0 || prev_rows < 0 || (prev_rows > 0 && !prev_ids))
     return fail(MI355_EINVAL, "decode_step_inputs: bad shape");
   const int64_t threads = (int64_t)rows * width;
   hipLaunchKernelGGL(decode_inputs_kernel, dim3((unsigned)ceil_div64(threads, 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), token_ids, positions, slots, context_lens, block_tables,
-                     packed, table_pool, rows, pool_rows, width, block_size, ilog2_exact(block_size));
+                     packed, table_pool, prev_ids, prev_rows, rows, pool_rows, width, block_size,
+                     ilog2_exact(block_size));
   return check_launch("decode_inputs_kernel");
 }
 

@@ -46,8 +46,8 @@ SIGNATURES = {
         c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
         c_int64, c_int64, c_int64, c_float, c_int32, c_void_p]),
     'mi355_decode_step_inputs': (c_int, [
-        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
-        c_int32, c_void_p]),
+        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+        c_int32, c_int32, c_int32, c_void_p]),
     'mi355_rope_kv_write': (c_int, [
         c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int32, c_void_p,
         c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,

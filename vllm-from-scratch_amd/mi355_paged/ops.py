@@ -247,7 +247,8 @@ def sample_argmax(logits: torch.Tensor, out: Optional[torch.Tensor] = None) -> t
 
 def sample_topk_topp(logits: torch.Tensor, temperature: torch.Tensor,
                      top_p: Optional[torch.Tensor] = None, top_k: Optional[torch.Tensor] = None,
-                     seed: int = 0, offset: int = 0, return_probs: bool = False):
+                     seed: int = 0, offset: int = 0, return_probs: bool = False,
+                     out: Optional[torch.Tensor] = None):
     """One draw per row after temperature / top-k / top-p filtering -> int32 [B]
     (and, with return_probs, the renormalised post-filter distribution [B, vocab] fp32)."""
     dev = require_device(logits, temperature, top_p, top_k)
@@ -262,7 +263,10 @@ def sample_topk_topp(logits: torch.Tensor, temperature: torch.Tensor,
         top_p = top_p.to(torch.float32).contiguous()
     if top_k is not None:
         top_k = top_k.to(torch.int32).contiguous()
-    out = torch.empty((B,), dtype=torch.int32, device=dev)
+    if out is None:
+        out = torch.empty((B,), dtype=torch.int32, device=dev)
+    elif out.dtype != torch.int32 or out.numel() < B or not out.is_contiguous():
+        raise ValueError("out must be a contiguous int32 vector of at least B entries")
     probs = torch.empty((B, V), dtype=torch.float32, device=dev) if return_probs else None
     with _on(dev):
         rc = lib.mi355_sample_topk_topp(
@@ -444,22 +448,28 @@ def silu_mul(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def decode_step_inputs(packed: torch.Tensor, table_pool: torch.Tensor, block_size: int):
+def decode_step_inputs(packed: torch.Tensor, table_pool: torch.Tensor, block_size: int,
+                       prev_ids: Optional[torch.Tensor] = None):
     """packed int32 [3, rows] = (token, position, pool row) -> (token_ids i64 [rows], positions i64
-    [rows], slots i64 [rows], context_lens i32 [rows], block_tables i32 [rows, width])."""
-    dev = require_device(packed, table_pool)
+    [rows], slots i64 [rows], context_lens i32 [rows], block_tables i32 [rows, width]).
+    A token entry -1-j is replaced by prev_ids[j] (int32, the previous step's sampled ids)."""
+    dev = require_device(packed, table_pool, prev_ids)
     lib = _lib.load()
     if packed.dtype != torch.int32 or packed.dim() != 2 or packed.shape[0] != 3 or not packed.is_contiguous():
         raise ValueError("packed must be a contiguous int32 [3, rows] tensor")
     if table_pool.dtype != torch.int32 or table_pool.dim() != 2 or not table_pool.is_contiguous():
         raise ValueError("table_pool must be a contiguous int32 [pool_rows, width] tensor")
+    if prev_ids is not None and (prev_ids.dtype != torch.int32 or prev_ids.dim() != 1 or not prev_ids.is_contiguous()):
+        raise ValueError("prev_ids must be a contiguous int32 vector")
     rows, width = packed.shape[1], table_pool.shape[1]
     i64 = torch.empty((3, rows), dtype=torch.int64, device=dev)
     ctx = torch.empty((rows,), dtype=torch.int32, device=dev)
     tables = torch.empty((rows, width), dtype=torch.int32, device=dev)
     with _on(dev):
         rc = lib.mi355_decode_step_inputs(i64[0].data_ptr(), i64[1].data_ptr(), i64[2].data_ptr(), ctx.data_ptr(),
-                                          tables.data_ptr(), packed.data_ptr(), table_pool.data_ptr(), rows,
+                                          tables.data_ptr(), packed.data_ptr(), table_pool.data_ptr(),
+                                          prev_ids.data_ptr() if prev_ids is not None else None,
+                                          prev_ids.numel() if prev_ids is not None else 0, rows,
                                           table_pool.shape[0], width, int(block_size), _stream(dev))
     _lib.check(rc, 'mi355_decode_step_inputs')
     return i64[0], i64[1], i64[2], ctx, tables

@@ -848,12 +848,16 @@ class DecodeStepGraph:
     attention launch is sized for contexts up to `max_context`.
     """
 
-    def __init__(self, model: "MiniTransformer", tables: DeviceBlockTables, rows: int, max_context: int):
+    def __init__(self, model: "MiniTransformer", tables: DeviceBlockTables, rows: int, max_context: int,
+                 prev_ids: Optional[torch.Tensor] = None):
         dev = tables.device
         self.model, self.tables, self.rows, self.max_context = model, tables, rows, max_context
         self.table_tensor = tables.tables            # the graph is bound to this storage
-        self.host = torch.zeros((3, rows), dtype=torch.int32).pin_memory()
-        self.host_np = self.host.numpy()
+        self.prev_ids = prev_ids                     # and to this one (token entries -1-j read prev_ids[j])
+        # two staging buffers: a step may be issued while the previous one, which read the other
+        # buffer, has not started on the device yet
+        self.host = [torch.zeros((3, rows), dtype=torch.int32).pin_memory() for _ in range(2)]
+        self.host_np = [h.numpy() for h in self.host]
         self.dev = torch.zeros((3, rows), dtype=torch.int32, device=dev)
         self.dev[1].fill_(-1)
         side = torch.cuda.Stream(device=dev)
@@ -867,23 +871,27 @@ class DecodeStepGraph:
             self.logits = self._body()
 
     def _body(self) -> torch.Tensor:
-        tok, pos, slots, ctx, tables = ops.decode_step_inputs(self.dev, self.table_tensor, self.model.block_size)
+        tok, pos, slots, ctx, tables = ops.decode_step_inputs(self.dev, self.table_tensor, self.model.block_size,
+                                                              self.prev_ids)
         plan = AttnPlan(total_tokens=self.rows, causal_index=None, cu_seqlens=None, causal_tokens=0,
                         max_causal_len=0, paged_index=None, paged_tables=tables, paged_context=ctx,
                         paged_rows=self.rows, max_context=self.max_context)
         return self.model.forward_planned(tok, pos, slots, plan)
 
-    def run(self, tokens: Sequence[int], positions: Sequence[int], rows: Sequence[int]) -> torch.Tensor:
-        """Logits [len(tokens), vocab] (a view of the graph's output buffer, valid until the next run)."""
+    def run(self, tokens: Sequence[int], positions: Sequence[int], rows: Sequence[int],
+            parity: int = 0) -> torch.Tensor:
+        """Logits [len(tokens), vocab] (a view of the graph's output buffer, valid until the next run).
+        `parity` picks the staging buffer; a caller that issues a step before the previous one has
+        finished alternates it."""
         n = len(tokens)
-        buf = self.host_np
+        buf = self.host_np[parity & 1]
         buf[0, :n] = tokens
         buf[1, :n] = positions
         buf[2, :n] = rows
         buf[0, n:] = 0
         buf[1, n:] = -1
         buf[2, n:] = 0
-        self.dev.copy_(self.host, non_blocking=True)
+        self.dev.copy_(self.host[parity & 1], non_blocking=True)
         self.graph.replay()
         return self.logits[:n]
 
@@ -906,16 +914,23 @@ class Sampler:
 
     @staticmethod
     def sample(logits: torch.Tensor, requests: List[Request]) -> List[int]:
-        n = len(requests)
-        if n == 0:
+        if not requests:
             return []
+        return [int(t) for t in Sampler.sample_device(logits, requests).tolist()]
+
+    @staticmethod
+    def sample_device(logits: torch.Tensor, requests: List[Request],
+                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The sampled ids as an int32 vector on the compute device, without a host read-back
+        (written to the head of `out` when given)."""
+        n = len(requests)
         dev = _compute_device(logits)
         rows = logits[:n].to(dev)
         temps = [float(r.temperature) for r in requests]
         greedy = [t == 0.0 for t in temps]
         picked = None
         if any(greedy):
-            picked = ops.sample_argmax(rows)
+            picked = ops.sample_argmax(rows, out=out if all(greedy) else None)
         if not all(greedy):
             top_p = [float(r.top_p) for r in requests]
             top_k = [int(getattr(r, 'top_k', 0) or 0) for r in requests]
@@ -924,36 +939,56 @@ class Sampler:
                 rows, torch.tensor([t if t != 0.0 else 1.0 for t in temps], dtype=torch.float32, device=dev),
                 torch.tensor(top_p, dtype=torch.float32, device=dev) if any(p < 1.0 for p in top_p) else None,
                 torch.tensor(top_k, dtype=torch.int32, device=dev) if any(k > 0 for k in top_k) else None,
-                seed=seed)
+                seed=seed, out=out if picked is None else None)
             if picked is None:
                 picked = drawn
             else:
-                picked = torch.where(torch.tensor(greedy, device=dev), picked, drawn)
-        return [int(t) for t in picked.tolist()]
+                picked = torch.where(torch.tensor(greedy, device=dev), picked[:n], drawn[:n])
+                if out is not None:
+                    out[:n].copy_(picked)
+        return picked[:n]
 
 
 # ---------------------------------------------------------------------------
 # engine
 # ---------------------------------------------------------------------------
 
+@dataclass
+class _InflightDecode:
+    """A decode step that has been issued: its requests in batch order, the pinned host vector its
+    sampled ids are being copied to, and the event that marks the copy's end."""
+    batch: List[Request]
+    ids_host: torch.Tensor
+    done: "torch.cuda.Event"
+
+
 class MiniVLLM:
     """schedule -> flatten -> model forward -> sample -> update
     (05_mini_vllm/mini_vllm.py:641-783).  Extra keyword arguments, all optional:
     reference_compat (see module docstring), dtype (parameter / KV cache dtype), decode_graphs
-    (replay pure-decode steps as captured HIP graphs) and enable_prefix_caching (reuse the KV
-    blocks of equal prompt prefixes; needs true-context attention, so not with reference_compat)."""
+    (replay pure-decode steps as captured HIP graphs), decode_lookahead (with decode_graphs: issue
+    the next pure-decode step before the host has read this one's tokens, see _step_decode_only)
+    and enable_prefix_caching (reuse the KV blocks of equal prompt prefixes; needs true-context
+    attention, so not with reference_compat)."""
 
     def __init__(self, vocab_size: int = 1000, hidden_size: int = 128, num_layers: int = 2,
                  num_heads: int = 4, intermediate_size: int = 512, num_kv_blocks: int = 256,
                  block_size: int = 16, max_num_seqs: int = 8, max_num_batched_tokens: int = 1024,
                  enable_chunked_prefill: bool = True, device: str = 'cpu',
                  reference_compat: bool = False, dtype: Optional[torch.dtype] = None,
-                 decode_graphs: bool = True, enable_prefix_caching: bool = False):
+                 decode_graphs: bool = True, enable_prefix_caching: bool = False,
+                 decode_lookahead: bool = True):
         self.device = torch.device(device)
         self.reference_compat = reference_compat
         # replay pure-decode steps as HIP graphs (device-resident engines only)
         self.decode_graphs = decode_graphs and self.device.type == 'cuda' and not reference_compat
         self._graphs: "OrderedDict[tuple, DecodeStepGraph]" = OrderedDict()
+        self.decode_lookahead = decode_lookahead and self.decode_graphs
+        self._inflight: Optional[_InflightDecode] = None   # a decode step issued, its tokens not read yet
+        self._launches = 0
+        self._ids_dev: Optional[torch.Tensor] = None       # where every captured step's sampler writes
+        self._ids_host: List[torch.Tensor] = []
+        self._ids_done: List[torch.cuda.Event] = []
         self.allocator = BlockAllocator(num_kv_blocks, block_size)
         self.scheduler = Scheduler(max_num_seqs=max_num_seqs,
                                    max_num_batched_tokens=max_num_batched_tokens,
@@ -990,36 +1025,98 @@ class MiniVLLM:
         bound = -(-max_context // 256) * 256
         tables = self._device_tables
         key = (rows, bound, tables.tables.data_ptr(), tables.tables.shape[1], self.model.k_cache.data_ptr(),
-               self.model.weights_version())
+               self.model.weights_version(), self._ids_dev.data_ptr())
         graph = self._graphs.get(key)
         if graph is None:
             for stale in [k for k in self._graphs if k[2:] != key[2:]]:
                 del self._graphs[stale]          # block tables, KV buffers or weights were replaced
             while len(self._graphs) >= self.MAX_GRAPHS:
                 self._graphs.popitem(last=False)
-            graph = self._graphs[key] = DecodeStepGraph(self.model, tables, rows, bound)
+            graph = self._graphs[key] = DecodeStepGraph(self.model, tables, rows, bound, self._ids_dev)
         else:
             self._graphs.move_to_end(key)
         return graph
 
+    def _launch_decode(self, batch: List[Request], tokens: List[int], positions: List[int]) -> "_InflightDecode":
+        """Issues one captured decode step, its sampling and the copy of the sampled ids to pinned
+        host memory; nothing here waits for the device."""
+        if self._device_tables is None:
+            dev = _compute_device(self.model.k_cache)
+            self._device_tables = DeviceBlockTables(dev, rows=max(8, self.scheduler.max_num_seqs))
+        if self._ids_dev is None:
+            dev = self._device_tables.device
+            cap = self.scheduler.max_num_seqs + 64          # every padded batch size fits
+            self._ids_dev = torch.zeros((cap,), dtype=torch.int32, device=dev)
+            self._ids_host = [torch.zeros((cap,), dtype=torch.int32).pin_memory() for _ in range(2)]
+            self._ids_done = [torch.cuda.Event() for _ in range(2)]
+        rows = self._device_tables.sync(batch)
+        parity = self._launches & 1
+        self._launches += 1
+        n = len(batch)
+        logits = self._decode_graph(n, max(positions) + 1).run(tokens, positions, rows, parity)
+        ids = self.sampler.sample_device(logits, batch, out=self._ids_dev)
+        self._ids_host[parity][:n].copy_(ids, non_blocking=True)
+        self._ids_done[parity].record()
+        return _InflightDecode(batch, self._ids_host[parity], self._ids_done[parity])
+
+    def _launch_ahead(self, cur: "_InflightDecode") -> Optional["_InflightDecode"]:
+        """The decode step after `cur`, issued while `cur` is still running: every request of
+        `cur` that cannot finish by length feeds the id `cur` samples for it, read on the device.
+        A request that turns out to have sampled the end-of-sequence id is only known after the
+        fact: its row of the step issued here is wasted and its result dropped.  None when the
+        scheduler would not produce a pure-decode step of exactly these requests."""
+        sch = self.scheduler
+        if sch.waiting:
+            return None
+        live = [(j, r) for j, r in enumerate(cur.batch) if not r.is_finished]
+        if len(live) != len(sch.running):
+            return None
+        ahead = [(j, r) for j, r in live if len(r.output_token_ids) + 1 < r.max_new_tokens]
+        if not ahead or len(ahead) > sch.max_num_seqs or len(ahead) > sch.max_num_batched_tokens:
+            return None
+        bs = sch.block_size
+        short = 0
+        for _, r in ahead:      # positions 0 .. num_computed_tokens + 1 must have blocks
+            short += max(0, -(-(r.num_computed_tokens + 2) // bs) - len(r.block_table))
+        if short > self.allocator.num_free:
+            return None
+        if short:
+            for _, r in ahead:
+                sch._ensure_blocks(r, 2)
+        return self._launch_decode([r for _, r in ahead], [-1 - j for j, _ in ahead],
+                                   [r.num_computed_tokens + 1 for _, r in ahead])
+
     def _step_decode_only(self):
         """A step in which every running request decodes one token, served by a captured
-        graph; None when the scheduler state needs the general path."""
-        batch = self.scheduler.schedule_decode_only()
-        if batch is None:
-            return None
-        if self._device_tables is None:
-            self._device_tables = DeviceBlockTables(_compute_device(self.model.k_cache),
-                                                    rows=max(8, self.scheduler.max_num_seqs))
-        rows = self._device_tables.sync(batch)
-        tokens = [r.output_token_ids[-1] for r in batch]
-        positions = [r.num_computed_tokens for r in batch]
-        logits = self._decode_graph(len(batch), max(positions) + 1).run(tokens, positions, rows)
-        next_tokens = self.sampler.sample(logits, batch)
+        graph; None when the scheduler state needs the general path.
+
+        With decode_lookahead the step after this one is issued before this one's tokens are
+        read back (its token inputs are this step's sampled ids, taken on the device), so the
+        host's scheduling, table upkeep and bookkeeping overlap the device's work instead of
+        alternating with it.  Results per request are those of the step-by-step loop; what
+        differs is when KV blocks are taken (one token earlier) and that a sequence ending on
+        the end-of-sequence id costs one wasted row in the step already in flight."""
+        cur, self._inflight = self._inflight, None
+        if cur is None:
+            batch = self.scheduler.schedule_decode_only()
+            if batch is None:
+                return None
+            cur = self._launch_decode(batch, [r.output_token_ids[-1] for r in batch],
+                                      [r.num_computed_tokens for r in batch])
+        nxt = self._launch_ahead(cur) if self.decode_lookahead else None
+        cur.done.synchronize()
+        ids = cur.ids_host[:len(cur.batch)].tolist()
+        batch, next_tokens = [], []
+        for req, tok in zip(cur.batch, ids):
+            if not req.is_finished:             # finished: ended on an earlier step's end-of-sequence id
+                batch.append(req)
+                next_tokens.append(tok)
         self.scheduler.update_decode_only(batch, next_tokens)
         for req in batch:
             if req.is_finished:
                 self._device_tables.release(req.request_id)
+        if nxt is not None and any(not r.is_finished for r in nxt.batch):
+            self._inflight = nxt
         return [(req.request_id, tok) for req, tok in zip(batch, next_tokens)]
 
     def step(self):
