@@ -180,6 +180,12 @@ def test_decode_grouped_query_matches_valu_kernel(ops, device, monkeypatch):
     (12, 4, 64, 16, [(20, 30)]),                                     # 3 heads per kv head -> padded to 4
     (40, 2, 128, 32, [(50, 9), (0, 33)]),                            # 20 heads per kv head: two head tiles, 1 token
     (4, 4, 64, 3, [(10, 29)]),                                       # block size not a power of two
+    # chunks of 48 or more query tokens go to the flash-attention kernel (128 query rows per workgroup)
+    (8, 8, 64, 16, [(0, 300), (130, 257), (1000, 129), (77, 1)]),    # no prefix; prefix not on a tile border
+    (16, 4, 128, 16, [(200, 140), (0, 64)]),                         # grouped heads, head_dim 128
+    (4, 2, 64, 3, [(10, 70)]),                                       # block size not a power of two
+    (8, 8, 128, 32, [(31, 200)]),                                    # block size 32
+    (4, 4, 64, 128, [(100, 130)]),                                   # a block holds two key tiles
 ])
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('layout', ['NHSD', 'NSHD'])
@@ -219,6 +225,59 @@ def test_paged_prefill_segments(ops, device, shape, dtype, layout):
             want = orc.paged_decode(qn[row], cn[0], cn[1], bt[s].tolist(), p0 + j + 1, BS, dtype=np.float64)
             np.testing.assert_allclose(got[row], want, **LOWP_TOL)
     assert (got[~owned] == 7.0).all()                                 # rows outside every segment are untouched
+
+
+@pytest.mark.parametrize('waves', ['4', '8'])
+def test_paged_prefill_long_chunk_matches_packed_prefill(ops, device, monkeypatch, waves):
+    """A whole prompt presented as one chunk over the paged cache (no prefix) must equal causal
+    prompt attention over the same K/V rows; with a prefix, the oracle row by row on a sample.
+    Both workgroup widths of the kernel."""
+    monkeypatch.setenv('MI355_PREFILL_WAVES', waves)
+    rng = np.random.default_rng(int(waves))
+    Hq, Hkv, D, BS, n = 8, 4, 128, 16, 700
+    per = (n + 333 + BS - 1) // BS
+    NB = 2 * per + 3
+    bt = rng.permutation(NB)[:2 * per].reshape(2, per).astype(np.int32)
+    cache = torch.from_numpy(rng.standard_normal((2, NB, Hkv, BS, D), dtype=np.float32)).to(torch.bfloat16)
+    q = torch.from_numpy(rng.standard_normal((2 * n, Hq, D), dtype=np.float32)).to(torch.bfloat16)
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=device)
+    tc = cache.to(device)
+    out = ops.paged_prefill(q.to(device), tc[0], tc[1], torch.from_numpy(bt).to(device), i32([0, n]), i32([n, n]),
+                            i32([0, 333]), n, n + 333)
+    got = out.float().cpu().numpy()
+    # segment 0: gather its K/V rows and run the packed causal kernel's oracle
+    cn = cache.float().numpy()
+    rows = [bt[0][t // BS] for t in range(n)]
+    k = np.stack([cn[0][rows[t], :, t % BS, :] for t in range(n)])
+    v = np.stack([cn[1][rows[t], :, t % BS, :] for t in range(n)])
+    want = orc.varlen_causal_attention(q[:n].float().numpy(), k, v, np.array([0, n], dtype=np.int32), dtype=np.float64)
+    np.testing.assert_allclose(got[:n], want, **LOWP_TOL)
+    qn = q.float().numpy()
+    for j in [0, 1, 63, 64, 127, 128, 255, 256, 511, 699]:
+        want = orc.paged_decode(qn[n + j], cn[0], cn[1], bt[1].tolist(), 333 + j + 1, BS, dtype=np.float64)
+        np.testing.assert_allclose(got[n + j], want, **LOWP_TOL)
+
+
+def test_paged_prefill_clamps_bad_block_ids(ops, device):
+    """Block ids outside the pool inside the used range give a wrong answer for that segment but
+    no out-of-bounds access and no effect on the other segment."""
+    rng = np.random.default_rng(5)
+    Hq, D, BS, n = 4, 64, 16, 100
+    per = (n + BS - 1) // BS
+    NB = 2 * per
+    bt = rng.permutation(NB).reshape(2, per).astype(np.int32)
+    cache = torch.from_numpy(rng.standard_normal((2, NB, Hq, BS, D), dtype=np.float32)).to(torch.bfloat16).to(device)
+    q = torch.from_numpy(rng.standard_normal((2 * n, Hq, D), dtype=np.float32)).to(torch.bfloat16).to(device)
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=device)
+    good = ops.paged_prefill(q, cache[0], cache[1], torch.from_numpy(bt).to(device), i32([0, n]), i32([n, n]),
+                             i32([0, 0]), n, n).clone()
+    bad = bt.copy()
+    bad[0, 2], bad[0, 4] = 10 ** 8, -5
+    got = ops.paged_prefill(q, cache[0], cache[1], torch.from_numpy(bad).to(device), i32([0, n]), i32([n, n]),
+                            i32([0, 0]), n, n)
+    torch.cuda.synchronize()
+    assert torch.equal(got[n:], good[n:])
+    assert torch.isfinite(got.float()).all()
 
 
 def test_paged_prefill_rejects_unsupported_shapes(ops, device):

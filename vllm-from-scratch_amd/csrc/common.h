@@ -33,6 +33,13 @@ bool prefill_mfma_supported(int dtype, int D);
 int prefill_mfma_launch(void* out, const void* q, const void* k, const void* v, int64_t q_stride_tok,
                         int64_t kv_stride_tok, const int32_t* cu_seqlens, int nseq, int total_tokens,
                         int max_seqlen, int Hq, int Hkv, int D, float scale, int dtype, hipStream_t stream);
+// The same kernel over block caches: segments of new query tokens behind a cached context.
+int prefill_mfma_paged_launch(void* out, const void* q, int64_t q_stride_tok, const void* k_cache,
+                              const void* v_cache, const int32_t* block_tables, const int32_t* seg_q0,
+                              const int32_t* seg_len, const int32_t* seg_pos0, int nseg, int max_q_len, int Hq,
+                              int Hkv, int D, int block_size, int max_blocks, int num_blocks, int max_context,
+                              int64_t s_blk, int64_t s_head, int64_t s_tok, float scale, int dtype,
+                              hipStream_t stream);
 
 static inline int ilog2_exact(int v) {  // log2(v) if v is a power of two, else -1
   if (v <= 0 || (v & (v - 1))) return -1;

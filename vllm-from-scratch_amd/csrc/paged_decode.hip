@@ -530,6 +530,18 @@ extern "C" int mi355_paged_prefill(void* out, const void* q, int64_t q_stride_to
   if (((uintptr_t)out | (uintptr_t)q | (uintptr_t)k_cache | (uintptr_t)v_cache) & 15)
     return fail(MI355_EINVAL, "paged_prefill: tensors must be 16-byte aligned");
 
+  // Chunks of many query tokens are dense work: the flash-attention kernel shares every K/V tile
+  // among 128 or 256 query rows through LDS.  Short chunks (a few tokens per sequence) keep the
+  // decode-shaped kernel below, whose tiles are 16 query columns wide.
+  // MI355_PAGED_PREFILL_MIN_Q moves the switch (A/B measurements).
+  if (prefill_mfma_supported(dtype, D) && scale > 0.f && max_q_len >= env_int("MI355_PAGED_PREFILL_MIN_Q", 48) &&
+      kv_stride_tok * 2 * (int64_t)block_size < (1LL << 32))
+    return prefill_mfma_paged_launch(out, q, q_stride_tok, k_cache, v_cache, block_tables, seg_q_start, seg_len,
+                                     seg_pos0, nseg, max_q_len, Hq, Hkv, D, block_size, max_blocks, num_blocks,
+                                     max_context,
+                                     kv_stride_block, kv_stride_head, kv_stride_tok, scale, dtype,
+                                     static_cast<hipStream_t>(stream));
+
   // Tile columns: tq query tokens x hgp (>= heads of the kv group, power of two, <= 16) heads.
   int hgp_shift = 0;
   while ((1 << hgp_shift) < gq && hgp_shift < 4) ++hgp_shift;

@@ -17,6 +17,10 @@
 //   O^T keeps the query on the lane too, so the online-softmax rescale of O is a
 //   per-lane scalar multiply.
 //
+// Two addressing modes share the kernel: packed (K/V rows of the prompt itself, [T, Hkv, D]) and
+// paged (query tokens of a later chunk, or of a prompt behind a cached prefix, attending to the
+// block cache through the sequence's block table; the chunk's own K/V rows are already in it).
+//
 // Numerics: fp32 scores / statistics / accumulation; P is rounded to the 16-bit
 // input type before the PV product (as every flash-attention kernel does).
 #include "common.h"
@@ -38,7 +42,15 @@ struct PrefillParams {
   const void* q;
   const void* k;
   const void* v;
-  const int32_t* cu;
+  const int32_t* cu;                   // packed mode: sequence boundaries [nseq + 1]
+  // paged mode: K/V are block caches read through a table; a segment is seg_len new query tokens
+  // whose first one sits at position seg_pos0 of its sequence (positions before it are cached)
+  const int32_t* bt;                   // [nseq, max_blocks]
+  const int32_t* seg_q0;
+  const int32_t* seg_len;
+  const int32_t* seg_pos0;
+  int64_t s_blk, s_head, s_tok;        // cache strides in elements
+  int max_blocks, block_size, bs_shift, num_blocks;
   int64_t q_stride_tok, kv_stride_tok;
   int nseq, n_qt_max, max_seqlen, Hq, Hkv, total_tokens;
   float scale_log2e;
@@ -103,7 +115,7 @@ __device__ __forceinline__ void pair_values(float x, float& lo, float& hi) {
 // Two workgroups (8 waves) per CU: with a 256-register budget the 64 accumulator registers of a
 // wave stay in VGPRs, where the softmax arithmetic reads and writes them directly (a tighter
 // budget parks them in AccVGPRs and pays a copy per register per use).
-template <class Tag, int D, int kWaves>
+template <class Tag, int D, int kWaves, bool PAGED>
 __global__ void __launch_bounds__(kWaves * kWave, 2) MI355_NO_PACKED_F32 prefill_mfma_kernel(const PrefillParams p) {
   constexpr int kQT = kQW * kWaves;   // query rows per workgroup
   constexpr int KS = D / 16;          // k-steps of the S^T product (over head_dim)
@@ -128,18 +140,23 @@ __global__ void __launch_bounds__(kWaves * kWave, 2) MI355_NO_PACKED_F32 prefill
   bid /= p.Hq;
   const int qt = p.n_qt_max - 1 - (bid % p.n_qt_max);   // long (late) tiles are issued first
   const int seq = bid / p.n_qt_max;
-  const int seq_start = p.cu[seq];
-  const int len = p.cu[seq + 1] - seq_start;
+  // nq query rows starting at row q_row0 of q / out; query i sits at position pos0 + i and sees
+  // keys 0 .. pos0 + i of the len = pos0 + nq keys
+  const int q_row0 = PAGED ? p.seg_q0[seq] : p.cu[seq];
+  const int nq = PAGED ? p.seg_len[seq] : p.cu[seq + 1] - q_row0;
+  const int pos0 = PAGED ? p.seg_pos0[seq] : 0;
+  const int seq_start = q_row0;                         // packed mode: K/V rows are the sequence's own
+  const int len = pos0 + nq;
   const int q0 = qt * kQT;
-  if (q0 >= len) return;
+  if (q0 >= nq) return;
   const int kvh = hq / (p.Hq / p.Hkv);
-  const int qw0 = q0 + wave * kQW;                      // first query row of this wave
-  const int my_q = qw0 + c;                             // this lane's query row (may be >= len)
+  const int qw0 = pos0 + q0 + wave * kQW;               // position of this wave's first query
+  const int my_q = qw0 + c;                             // this lane's query position (may be >= len)
 
   // Q fragments (B operand of S^T = K.Q^T): lane (c,h), k-step s holds Q[c][16s + 8h .. +8).
   u32x4 qf[KS];
   {
-    const int row = seq_start + min(my_q, len - 1);
+    const int row = q_row0 + min(my_q, len - 1) - pos0;
     const char* src = static_cast<const char*>(p.q) + ((int64_t)row * p.q_stride_tok + (int64_t)hq * D) * 2;
 #pragma unroll
     for (int s = 0; s < KS; ++s) qf[s] = *reinterpret_cast<const u32x4*>(src + (16 * s + 8 * h) * 2);
@@ -152,40 +169,70 @@ __global__ void __launch_bounds__(kWaves * kWave, 2) MI355_NO_PACKED_F32 prefill
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m_run = -1.0e30f, l_run = 0.f;
 
-  const int kv_end = min(len, q0 + kQT);                // causal: no key past the tile's last query
+  const int kv_end = min(len, pos0 + q0 + kQT);         // causal: no key past the tile's last query
   const int ntiles = (kv_end + kKT - 1) / kKT;
   const char* kbase = static_cast<const char*>(p.k);
   const char* vbase = static_cast<const char*>(p.v);
 
-  // A thread always stages the same (key, chunk) positions of a tile, so a load address is a
-  // wave-uniform tile base plus a per-thread 32-bit offset that only changes in the sequence's
-  // last, partial tile (rows past the end re-read the last row; they are masked below).
+  // A thread always stages the same (key, chunk) positions of a tile.  Packed mode: a load address
+  // is a wave-uniform tile base plus a per-thread 32-bit offset that only changes in the
+  // sequence's last, partial tile (rows past the end re-read the last row; they are masked
+  // below).  Paged mode: the key's block id comes from the table (fetched one tile ahead, so the
+  // dependent K/V loads do not wait for it) and the address is block * stride + row in block.
   u32x4 kreg[LOADS], vreg[LOADS];
   const uint32_t rowbytes = (uint32_t)p.kv_stride_tok * 2u;
   uint32_t voff[LOADS];
+  int32_t blk[LOADS];
+  const int32_t* bt_row = PAGED ? p.bt + (int64_t)seq * p.max_blocks : nullptr;
 #pragma unroll
   for (int i = 0; i < LOADS; ++i) {
     const int ch = tid + i * (kWaves * kWave);
-    voff[i] = (uint32_t)(ch / CPR) * rowbytes + (uint32_t)(kvh * D + (ch % CPR) * 8) * 2u;
+    voff[i] = PAGED ? (uint32_t)((int64_t)kvh * p.s_head + (ch % CPR) * 8) * 2u
+                    : (uint32_t)(ch / CPR) * rowbytes + (uint32_t)(kvh * D + (ch % CPR) * 8) * 2u;
+    blk[i] = 0;
   }
+  auto block_of = [&](int key) __attribute__((always_inline)) {
+    return p.bs_shift >= 0 ? key >> p.bs_shift : key / p.block_size;
+  };
+  auto fetch_blocks = [&](int tile) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+      const int key = min(tile * kKT + (tid + i * (kWaves * kWave)) / CPR, len - 1);
+      blk[i] = min(max(bt_row[block_of(key)], 0), p.num_blocks - 1);   // a bad id must not leave the pool
+    }
+  };
   auto issue_loads = [&](int tile) __attribute__((always_inline)) {
-    const int64_t base = (int64_t)(seq_start + tile * kKT) * rowbytes;
-    const char* kb = kbase + base;
-    const char* vb = vbase + base;
-    const int last = len - 1 - tile * kKT;                          // tile-relative index of the last valid row
-    if (last >= kKT - 1) {
+    if constexpr (PAGED) {
+      const uint32_t tokbytes = (uint32_t)p.s_tok * 2u;
+      const int64_t blkbytes = p.s_blk * 2;
 #pragma unroll
       for (int i = 0; i < LOADS; ++i) {
-        kreg[i] = *reinterpret_cast<const u32x4*>(kb + voff[i]);
-        vreg[i] = *reinterpret_cast<const u32x4*>(vb + voff[i]);
+        const int key = min(tile * kKT + (tid + i * (kWaves * kWave)) / CPR, len - 1);
+        const int within = key - block_of(key) * p.block_size;
+        const int64_t off = (int64_t)blk[i] * blkbytes + (uint32_t)within * tokbytes + voff[i];
+        kreg[i] = *reinterpret_cast<const u32x4*>(kbase + off);
+        vreg[i] = *reinterpret_cast<const u32x4*>(vbase + off);
       }
+      if ((tile + 1) * kKT < len) fetch_blocks(tile + 1);
     } else {
+      const int64_t base = (int64_t)(seq_start + tile * kKT) * rowbytes;
+      const char* kb = kbase + base;
+      const char* vb = vbase + base;
+      const int last = len - 1 - tile * kKT;                          // tile-relative index of the last valid row
+      if (last >= kKT - 1) {
 #pragma unroll
-      for (int i = 0; i < LOADS; ++i) {
-        const int ch = tid + i * (kWaves * kWave);
-        const uint32_t off = (uint32_t)min(ch / CPR, last) * rowbytes + (uint32_t)(kvh * D + (ch % CPR) * 8) * 2u;
-        kreg[i] = *reinterpret_cast<const u32x4*>(kb + off);
-        vreg[i] = *reinterpret_cast<const u32x4*>(vb + off);
+        for (int i = 0; i < LOADS; ++i) {
+          kreg[i] = *reinterpret_cast<const u32x4*>(kb + voff[i]);
+          vreg[i] = *reinterpret_cast<const u32x4*>(vb + voff[i]);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < LOADS; ++i) {
+          const int ch = tid + i * (kWaves * kWave);
+          const uint32_t off = (uint32_t)min(ch / CPR, last) * rowbytes + (uint32_t)(kvh * D + (ch % CPR) * 8) * 2u;
+          kreg[i] = *reinterpret_cast<const u32x4*>(kb + off);
+          vreg[i] = *reinterpret_cast<const u32x4*>(vb + off);
+        }
       }
     }
   };
@@ -204,6 +251,7 @@ __global__ void __launch_bounds__(kWaves * kWave, 2) MI355_NO_PACKED_F32 prefill
   // Tile t is reduced from buffer t&1 while tile t+1 sits in registers; at the end of the step
   // those registers go to the other buffer (last read in step t-1, which every wave has left)
   // and the loads of tile t+2 are issued.
+  if constexpr (PAGED) fetch_blocks(0);
   issue_loads(0);
   write_lds(0);
   if (ntiles > 1) issue_loads(1);
@@ -307,7 +355,7 @@ __global__ void __launch_bounds__(kWaves * kWave, 2) MI355_NO_PACKED_F32 prefill
   // ---- normalise and store: lane (c,h) holds O[my_q][32*dt + 8*(r>>2) + 4*h + (r&3)]
   if (my_q < len) {
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
-    char* dst = static_cast<char*>(p.out) + ((int64_t)(seq_start + my_q) * p.Hq + hq) * D * 2;
+    char* dst = static_cast<char*>(p.out) + ((int64_t)(q_row0 + my_q - pos0) * p.Hq + hq) * D * 2;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -321,23 +369,26 @@ __global__ void __launch_bounds__(kWaves * kWave, 2) MI355_NO_PACKED_F32 prefill
   }
 }
 
-template <class Tag, int D, int kWaves>
+template <class Tag, int D, int kWaves, bool PAGED>
 int launch_w(PrefillParams p, hipStream_t s) {
   p.n_qt_max = (p.max_seqlen + kQW * kWaves - 1) / (kQW * kWaves);
   const int64_t grid = (int64_t)p.nseq * p.n_qt_max * p.Hq;
-  hipLaunchKernelGGL((prefill_mfma_kernel<Tag, D, kWaves>), dim3((unsigned)grid), dim3(kWaves * kWave), 0, s, p);
+  if (grid >= (1LL << 31)) return fail(MI355_EINVAL, "prefill: grid too large");
+  hipLaunchKernelGGL((prefill_mfma_kernel<Tag, D, kWaves, PAGED>), dim3((unsigned)grid), dim3(kWaves * kWave), 0, s,
+                     p);
   return check_launch("prefill_mfma_kernel");
 }
 
 // 256-row workgroups stage every K/V tile once for twice the queries (half the LDS writes and
 // global loads per product), but their waves idle more on the diagonal and there are half as
-// many of them: they take over once the launch still fills the chip several times.
-template <class Tag, int D>
-int launch(const PrefillParams& p, hipStream_t s) {
-  static const int force = env_int("MI355_PREFILL_WAVES", 0);
+// many of them: they take over for long contexts once the launch still fills the chip.
+// max_context = the longest key range a query tile walks.
+template <class Tag, int D, bool PAGED>
+int launch(const PrefillParams& p, int max_context, hipStream_t s) {
+  const int force = env_int("MI355_PREFILL_WAVES", 0);
   const int64_t wgs8 = (int64_t)p.nseq * ((p.max_seqlen + 8 * kQW - 1) / (8 * kQW)) * p.Hq;
-  const bool big = force ? force == 8 : (p.max_seqlen >= 4096 && wgs8 >= 2 * 256);
-  return big ? launch_w<Tag, D, 8>(p, s) : launch_w<Tag, D, 4>(p, s);
+  const bool big = force ? force == 8 : (max_context >= 4096 && p.max_seqlen >= 8 * kQW && wgs8 >= 2 * 256);
+  return big ? launch_w<Tag, D, 8, PAGED>(p, s) : launch_w<Tag, D, 4, PAGED>(p, s);
 }
 
 }  // namespace
@@ -364,8 +415,52 @@ int prefill_mfma_launch(void* out, const void* q, const void* k, const void* v, 
   p.Hkv = Hkv;
   p.total_tokens = total_tokens;
   p.scale_log2e = scale * 1.4426950408889634f;
-  if (dtype == MI355_BF16) return D == 64 ? launch<BF16, 64>(p, stream) : launch<BF16, 128>(p, stream);
-  return D == 64 ? launch<F16, 64>(p, stream) : launch<F16, 128>(p, stream);
+  p.bt = nullptr;
+  p.seg_q0 = p.seg_len = p.seg_pos0 = nullptr;
+  p.s_blk = p.s_head = p.s_tok = 0;
+  p.max_blocks = p.block_size = p.num_blocks = 0;
+  p.bs_shift = -1;
+  if (dtype == MI355_BF16)
+    return D == 64 ? launch<BF16, 64, false>(p, max_seqlen, stream) : launch<BF16, 128, false>(p, max_seqlen, stream);
+  return D == 64 ? launch<F16, 64, false>(p, max_seqlen, stream) : launch<F16, 128, false>(p, max_seqlen, stream);
+}
+
+// Paged mode: nseg segments of new query tokens (rows seg_q0[s] .. +seg_len[s]-1 of q / out, first
+// token at position seg_pos0[s]) over block caches with the given element strides.
+int prefill_mfma_paged_launch(void* out, const void* q, int64_t q_stride_tok, const void* k_cache,
+                              const void* v_cache, const int32_t* block_tables, const int32_t* seg_q0,
+                              const int32_t* seg_len, const int32_t* seg_pos0, int nseg, int max_q_len, int Hq,
+                              int Hkv, int D, int block_size, int max_blocks, int num_blocks, int max_context,
+                              int64_t s_blk, int64_t s_head, int64_t s_tok, float scale, int dtype,
+                              hipStream_t stream) {
+  PrefillParams p;
+  p.num_blocks = num_blocks;
+  p.out = out;
+  p.q = q;
+  p.k = k_cache;
+  p.v = v_cache;
+  p.cu = nullptr;
+  p.bt = block_tables;
+  p.seg_q0 = seg_q0;
+  p.seg_len = seg_len;
+  p.seg_pos0 = seg_pos0;
+  p.s_blk = s_blk;
+  p.s_head = s_head;
+  p.s_tok = s_tok;
+  p.max_blocks = max_blocks;
+  p.block_size = block_size;
+  p.bs_shift = ilog2_exact(block_size);
+  p.q_stride_tok = q_stride_tok;
+  p.kv_stride_tok = s_tok;
+  p.nseq = nseg;
+  p.max_seqlen = max_q_len;
+  p.Hq = Hq;
+  p.Hkv = Hkv;
+  p.total_tokens = 0;
+  p.scale_log2e = scale * 1.4426950408889634f;
+  if (dtype == MI355_BF16)
+    return D == 64 ? launch<BF16, 64, true>(p, max_context, stream) : launch<BF16, 128, true>(p, max_context, stream);
+  return D == 64 ? launch<F16, 64, true>(p, max_context, stream) : launch<F16, 128, true>(p, max_context, stream);
 }
 
 }  // namespace mi355
