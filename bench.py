@@ -157,7 +157,10 @@ def main():
     inp = build_inputs(cfg, device, seed=rank, sets=2 if args.config == 'metric' else 4)
     nsets = len(inp['pools'])
     out = torch.empty((B, H, D), dtype=torch.bfloat16, device=device)
-    gather = dp.OverlappedTokenGather(B, device, single_rank_collective=use_dist, every=args.gather_every)
+    # BENCH_NATIVE_RCCL=1: the collective goes through the library's own communicator (mi355_dp_*)
+    native = dp.NativeComm(device) if use_dist and backend == 'nccl' and os.environ.get('BENCH_NATIVE_RCCL') else None
+    gather = dp.OverlappedTokenGather(B, device, single_rank_collective=use_dist, every=args.gather_every,
+                                      native=native)
 
     ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -237,6 +240,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, inp)
         print(json.dumps(line), flush=True)
+    if native is not None:
+        torch.cuda.synchronize()
+        native.close()
     if use_dist:
         dist.destroy_process_group()
 

@@ -46,6 +46,7 @@ extern "C" {
 #define MI355_EINVAL (-1)      /* bad shape / stride / null pointer            */
 #define MI355_EUNSUPPORTED (-2) /* shape outside the compiled kernel set       */
 #define MI355_EWORKSPACE (-3)   /* workspace missing or too small              */
+#define MI355_ECOLLECTIVE (-4)  /* the collective library reported an error     */
 
 /* Library ABI version (== MI355_ABI_VERSION the library was built with). */
 int mi355_abi_version(void);
@@ -282,6 +283,23 @@ int mi355_paged_prefill(void* out, const void* q, int64_t q_stride_tok,
                         int32_t block_size, int32_t max_blocks, int32_t num_blocks, int32_t max_context,
                         int64_t kv_stride_block, int64_t kv_stride_head, int64_t kv_stride_tok,
                         float scale, int32_t dtype, void* stream);
+
+/*
+ * Data-parallel exchange of the sampled token ids, one process per GPU, over RCCL (xGMI inside a
+ * node).  No counterpart in the reference, which is single-process and single-device (its only
+ * collective is a commented-out all-reduce, 03_moe/mini_moe.py:356-357): sequences are sharded
+ * over ranks and each rank's ids are all-gathered so that every rank holds the whole batch's.
+ * RCCL is bound at run time; without librccl.so.1 these return MI355_EUNSUPPORTED.
+ *   mi355_dp_unique_id: rank 0 fills id_out[128]; the caller passes those bytes to every rank.
+ *   mi355_dp_init: every rank, with its HIP device current, joins; *comm_out is the communicator.
+ *   mi355_dp_allgather_i32: recv[r * count .. +count) = rank r's send[0 .. count), on `stream`
+ *     (asynchronous; buffers are device memory and stay valid until the stream reaches the end).
+ *   mi355_dp_destroy: releases the communicator.
+ */
+int mi355_dp_unique_id(void* id_out);
+int mi355_dp_init(const void* id, int32_t nranks, int32_t rank, void** comm_out);
+int mi355_dp_allgather_i32(void* comm, const int32_t* send, int32_t* recv, int64_t count, void* stream);
+int mi355_dp_destroy(void* comm);
 
 #ifdef __cplusplus
 }

@@ -304,3 +304,26 @@ def test_captured_decode_keeps_its_own_workspace(ops, device):
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, want) and need >= 0 and len(junk) == 8
+
+
+def test_native_rccl_communicator_one_rank(device):
+    """mi355_dp_*: unique id, communicator, all-gather and teardown on a one-rank RCCL communicator
+    (a one-GPU machine cannot hold more ranks); through the overlapped gather as well."""
+    from mi355_paged import dp
+    comm = dp.NativeComm(device)
+    assert (comm.rank, comm.world) == (0, 1)
+    send = torch.arange(100, 356, dtype=torch.int32, device=device)
+    recv = torch.zeros(256, dtype=torch.int32, device=device)
+    comm.all_gather_i32(send, recv)
+    torch.cuda.synchronize()
+    assert torch.equal(recv, send)
+    with pytest.raises(ValueError):
+        comm.all_gather_i32(send, recv[:100])
+    g = dp.OverlappedTokenGather(8, device, single_rank_collective=True, every=3, native=comm)
+    for i in range(10):
+        g.send_buffer(i).copy_(torch.arange(8, dtype=torch.int32, device=device) + 10 * i)
+        g.launch(i)
+    g.drain()
+    assert g.result(9).tolist() == [90 + j for j in range(8)]
+    assert g.result(7).tolist() == [70 + j for j in range(8)]
+    comm.close()

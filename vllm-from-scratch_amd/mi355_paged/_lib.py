@@ -55,6 +55,10 @@ SIGNATURES = {
     'mi355_rmsnorm': (c_int, [
         c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_float, c_int32, c_int32,
         c_int32, c_void_p]),
+    'mi355_dp_unique_id': (c_int, [c_void_p]),
+    'mi355_dp_init': (c_int, [c_void_p, c_int32, c_int32, c_void_p]),
+    'mi355_dp_allgather_i32': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    'mi355_dp_destroy': (c_int, [c_void_p]),
     'mi355_silu_mul': (c_int, [
         c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p]),
 }

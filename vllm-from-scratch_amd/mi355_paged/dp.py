@@ -63,6 +63,63 @@ def all_gather_token_ids(local_ids: torch.Tensor, total: Optional[int] = None,
     return torch.cat([recv[r * widest:r * widest + s] for r, s in enumerate(sizes)])
 
 
+class NativeComm:
+    """The library's own RCCL communicator (mi355_dp_*): one rank per process, bound to the
+    current HIP device.  A torch.distributed group (any backend) is used once, to hand rank 0's
+    unique id to the other ranks; the collectives themselves are single library calls on a HIP
+    stream, with none of torch.distributed's per-call stream switching.
+    """
+
+    def __init__(self, device, group=None):
+        import ctypes
+        from . import _lib
+        self._lib, self._check = _lib.load(), _lib.check
+        self.device = torch.device(device)
+        on = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if on else 0
+        self.world = dist.get_world_size(group) if on else 1
+        uid = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            self._check(self._lib.mi355_dp_unique_id(uid), 'mi355_dp_unique_id')
+        if self.world > 1:
+            box = [uid.raw]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            uid = ctypes.create_string_buffer(box[0], 128)
+        comm = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            self._check(self._lib.mi355_dp_init(uid, self.world, self.rank, ctypes.byref(comm)), 'mi355_dp_init')
+        self._comm = comm
+
+    def all_gather_i32(self, send: torch.Tensor, recv: torch.Tensor, stream=None) -> None:
+        """recv[r * n : (r + 1) * n] = rank r's send[:n]; asynchronous on `stream` (default: current)."""
+        if send.dtype != torch.int32 or recv.dtype != torch.int32 or not send.is_cuda or not recv.is_cuda \
+                or not send.is_contiguous() or not recv.is_contiguous() or recv.numel() != send.numel() * self.world:
+            raise ValueError("send / recv must be contiguous int32 device vectors, recv world times as long")
+        stream = stream if stream is not None else torch.cuda.current_stream(self.device)
+        with torch.cuda.device(self.device):
+            self._check(self._lib.mi355_dp_allgather_i32(self._comm, send.data_ptr(), recv.data_ptr(),
+                                                         send.numel(), stream.cuda_stream), 'mi355_dp_allgather_i32')
+
+    def close(self) -> None:
+        if self._comm is not None and self._comm.value:
+            self._check(self._lib.mi355_dp_destroy(self._comm), 'mi355_dp_destroy')
+        self._comm = None
+
+
+class _EventWork:
+    """What OverlappedTokenGather needs of a collective handle, for a native collective issued on
+    a side stream: has it finished (host-side query), and make the current stream wait for it."""
+
+    def __init__(self, event, device):
+        self.event, self.device = event, device
+
+    def is_completed(self) -> bool:
+        return self.event.query()
+
+    def wait(self) -> None:
+        torch.cuda.current_stream(self.device).wait_event(self.event)
+
+
 class OverlappedTokenGather:
     """All-gather of every step's sampled ids that does not stall the step after it.
 
@@ -84,10 +141,12 @@ class OverlappedTokenGather:
     SLOTS = 4
 
     def __init__(self, n_local: int, device, dtype=torch.int32, group=None, single_rank_collective=False,
-                 every: int = 1):
+                 every: int = 1, native: Optional[NativeComm] = None):
         """`every` > 1 batches the exchange: the ids of `every` consecutive steps travel in one
         collective, issued after the last of them (or by `flush()` / `drain()`), so its fixed cost
-        (a host call, a kernel and two stream dependencies) is paid once per group of steps."""
+        (a host call, a kernel and two stream dependencies) is paid once per group of steps.
+        `native`: a NativeComm to run the collective through (on a side stream of its own) instead
+        of torch.distributed."""
         if every < 1:
             raise ValueError(f"every must be >= 1, got {every}")
         self.group = group
@@ -95,8 +154,15 @@ class OverlappedTokenGather:
         self.active = dist.is_available() and dist.is_initialized() and (
             dist.get_world_size(group) > 1 or single_rank_collective)
         self.world = dist.get_world_size(group) if self.active else 1
+        self.native = native
+        if native is not None:
+            if dtype != torch.int32:
+                raise ValueError("the native collective moves int32 ids")
+            self.active, self.world = native.world > 1 or single_rank_collective, native.world
+            self.side = torch.cuda.Stream(device=device)
         # gloo cannot move device memory: stage through the host, synchronously (CPU tests, rehearsals)
-        self.host_staged = self.active and dist.get_backend(group) == 'gloo' and torch.device(device).type == 'cuda'
+        self.host_staged = (self.active and native is None and dist.get_backend(group) == 'gloo'
+                            and torch.device(device).type == 'cuda')
         self.send = [torch.zeros((every * n_local,), dtype=dtype, device=device) for _ in range(self.SLOTS)]
         self.recv = [torch.zeros((self.world * every * n_local,), dtype=dtype, device=device) if self.active
                      else None for _ in range(self.SLOTS)]
@@ -130,6 +196,14 @@ class OverlappedTokenGather:
     def _exchange(self, slot: int) -> None:
         self.pending[slot] = False
         if not self.active:
+            return
+        if self.native is not None:
+            dev = self.native.device
+            self.side.wait_stream(torch.cuda.current_stream(dev))      # the sampler has written the ids
+            self.native.all_gather_i32(self.send[slot], self.recv[slot], stream=self.side)
+            done = torch.cuda.Event()
+            done.record(self.side)
+            self.work[slot] = _EventWork(done, dev)
             return
         if self.host_staged:
             out = torch.empty((self.recv[slot].numel(),), dtype=self.recv[slot].dtype)
