@@ -3,7 +3,7 @@
 #   tools/collect_profiles.sh <tag>      (writes gpurun_out/<tag>/...)
 # Kernel-trace passes and counter (--pmc) passes are separate rocprofv3 runs.
 set -e
-TAG=${1:-r1c}
+TAG=${1:-r1e}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -24,17 +24,20 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/
   python3 tools/bench_gqa.py > "$OUT/gqa_under_rocprof.txt" 2> "$OUT/trace_gqa.log"
 MLA_TARGETS=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_mla" -o mla -- \
   python3 tools/bench_mla.py 256 16 4096 > "$OUT/mla_under_rocprof.txt" 2> "$OUT/trace_mla.log"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_prefill" -o prefill -- \
-  python3 tools/bench_prefill.py 4 8192 8 8 64 > "$OUT/prefill_under_rocprof.txt" 2> "$OUT/trace_prefill.log"
+BENCH_MFMA_ONLY=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_prefill" -o prefill -- \
+  python3 tools/bench_prefill.py 4 8192 32 8 128 > "$OUT/prefill_under_rocprof.txt" 2> "$OUT/trace_prefill.log"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_paged_prefill" -o pp -- \
+  python3 tools/bench_paged_prefill.py > "$OUT/paged_prefill_under_rocprof.txt" 2> "$OUT/trace_paged_prefill.log"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_engine" -o engine -- \
+  python3 tools/profile_engine.py 256 512 64 > "$OUT/engine_under_rocprof.txt" 2> "$OUT/trace_engine.log"
 
 step counters: HBM traffic of the decode kernel, MFMA activity of the prefill kernel
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o fetch -- \
   python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2> "$OUT/pmc_fetch.log"
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o write -- \
   python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2> "$OUT/pmc_write.log"
-timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE \
-  --output-format csv -d "$OUT/pmc_prefill" -o prefill -- \
-  python3 tools/bench_prefill.py 4 8192 8 8 64 > /dev/null 2> "$OUT/pmc_prefill.log"
+BENCH_MFMA_ONLY=1 tools/pmc_sq.sh "$OUT/pmc_prefill_d128" prefill_mfma tools/bench_prefill.py 4 8192 32 8 128 > "$OUT/pmc_prefill_d128.txt"
+BENCH_MFMA_ONLY=1 tools/pmc_sq.sh "$OUT/pmc_prefill_d64" prefill_mfma tools/bench_prefill.py 2 16384 8 8 64 > "$OUT/pmc_prefill_d64.txt"
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_mla_fetch" -o fetch -- \
   python3 tools/bench_mla.py 256 16 4096 > /dev/null 2> "$OUT/pmc_mla_fetch.log"
 
@@ -47,9 +50,18 @@ step secondary benchmarks
   timeout -k 10 200 python3 tools/bench_locality.py
   timeout -k 10 200 python3 tools/tune_decode.py c2 256
   for a in "64 16 4096" "256 16 4096" "128 16 8192"; do MLA_TARGETS=0,0 timeout -k 10 120 python3 tools/bench_mla.py $a | tail -1; done
-  for a in "16 2048 8 8 64" "4 8192 8 8 64" "8 4096 16 2 128"; do timeout -k 10 120 python3 tools/bench_prefill.py $a; done
+  for a in "16 2048 8 8 64" "2 16384 8 8 64" "16 2048 32 8 128" "4 8192 32 8 128" "64 512 32 8 128"; do BENCH_MFMA_ONLY=1 timeout -k 10 120 python3 tools/bench_prefill.py $a; done
+  timeout -k 10 120 python3 tools/bench_prefill.py 16 2048 8 8 64 | grep valu
+  for a in "8 1024 3072 32 8 128" "8 1024 3072 8 8 64" "32 256 256 8 8 64" "64 64 1024 8 8 64"; do timeout -k 10 120 python3 tools/bench_paged_prefill.py $a; done
+  timeout -k 10 200 python3 tools/bench_dtypes.py
   timeout -k 10 200 python3 tools/bench_engine.py 256 512 32
   timeout -k 10 200 python3 tools/bench_engine.py 128 256 64
   timeout -k 10 200 python3 tools/bench_engine.py 8 4096 8 1024
+  export MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0
+  echo "one-rank RCCL communicator (BENCH_FORCE_DIST=1): gather every 4 steps, every step, native every step, none"
+  BENCH_FORCE_DIST=1 timeout -k 10 200 python3 bench.py --no-cpu-baseline | cut -c1-200
+  BENCH_FORCE_DIST=1 timeout -k 10 200 python3 bench.py --no-cpu-baseline --gather-every 1 | cut -c1-200
+  BENCH_FORCE_DIST=1 BENCH_NATIVE_RCCL=1 timeout -k 10 200 python3 bench.py --no-cpu-baseline --gather-every 1 | cut -c1-200
+  timeout -k 10 200 python3 bench.py --no-cpu-baseline | cut -c1-200
 } > "$OUT/secondary.txt" 2> "$OUT/secondary.err"
 find "$OUT" -name '*.csv' | head -40 >&2
