@@ -1,0 +1,40 @@
+"""Decode-kernel bandwidth at small batches and long contexts (token-split path + merge):
+python tools/bench_small_batch.py"""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'vllm-from-scratch_amd'))
+import torch
+from mi355_paged import ops
+
+dev = torch.device('cuda', 0)
+BS = 16
+for Hq, Hkv, D in ((8, 8, 64), (32, 8, 128)):
+    for B, S in ((1, 8192), (1, 32768), (4, 8192), (4, 32768), (16, 8192), (16, 32768), (64, 1024), (32, 2048)):
+        g = torch.Generator(device=dev).manual_seed(0)
+        per = S // BS
+        NB = B * per + 8
+        nbytes = B * S * Hkv * D * 2 * 2 + 2 * B * Hq * D * 2 + 4 * B * per
+        sets = max(2, min(8, int(600e6 // nbytes) + 1))          # rotate enough pools to defeat the 256 MiB cache
+        pools = []
+        for _ in range(sets):
+            kc = torch.randn((NB, Hkv, BS, D), generator=g, device=dev).to(torch.bfloat16)
+            vc = torch.randn((NB, Hkv, BS, D), generator=g, device=dev).to(torch.bfloat16)
+            bt = torch.randperm(NB, generator=g, device=dev)[:B * per].view(B, per).to(torch.int32).contiguous()
+            pools.append((kc, vc, bt))
+        q = torch.randn((B, Hq, D), generator=g, device=dev).to(torch.bfloat16)
+        ctx = torch.full((B,), S, dtype=torch.int32, device=dev)
+        out = torch.empty_like(q)
+        n = 40
+        for i in range(6):
+            ops.paged_decode(q, *pools[i % sets], ctx, S, out=out)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for i in range(n):
+            ops.paged_decode(q, *pools[i % sets], ctx, S, out=out)
+        b.record()
+        torch.cuda.synchronize()
+        us = a.elapsed_time(b) / n * 1e3
+        print(f"Hq={Hq} Hkv={Hkv} D={D} B={B:3d} ctx={S:6d} ({nbytes / 1e6:7.1f} MB): {us:7.1f} us  "
+              f"{nbytes / us / 1e3:6.0f} GB/s ({nbytes / us / 1e3 / 80:.1f}% of 8 TB/s)", flush=True)
+        del pools

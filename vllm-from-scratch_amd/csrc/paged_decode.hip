@@ -285,6 +285,60 @@ __global__ void __launch_bounds__(256) paged_decode_merge_kernel(const DecodePar
   }
 }
 
+// The same combination for many splits (small batches of long contexts): one workgroup per
+// (sequence, query head); its threads are (split group, 4 output dims), so the chain of dependent
+// loads a thread walks is nsplit / groups long instead of nsplit, and the groups meet in LDS.
+template <class Tag, int D>
+__global__ void __launch_bounds__(256) paged_decode_merge_wide_kernel(const DecodeParams p) {
+  constexpr int kVec = 4, kDv = D / kVec, kGroups = 256 / kDv;
+  static_assert(kDv <= 64 && 256 % kDv == 0, "head_dim");
+  __shared__ float s_red[kGroups][kDv][kVec + 1];
+  __shared__ float s_max[4];
+  const int tid = threadIdx.x, dv = tid % kDv, grp = tid / kDv;
+  const int64_t bh = blockIdx.x;
+  const int b = (int)(bh / p.Hq);
+  const int ctx = max(0, min(p.ctx[b], p.max_ctx));
+  const int nvalid = min(p.nsplit, (ctx + p.tps - 1) / p.tps);
+  const float* ml = p.ws_ml + bh * p.nsplit * 2;
+  const float* pa = p.ws_acc + bh * p.nsplit * D + dv * kVec;
+  float M = kNegBig;
+  for (int s = tid; s < nvalid; s += 256) M = fmaxf(M, ml[2 * s]);
+  for (int off = 32; off > 0; off >>= 1) M = fmaxf(M, __shfl_xor(M, off));
+  if ((tid & 63) == 0) s_max[tid >> 6] = M;
+  __syncthreads();
+  M = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+  float den = 0.f, o[kVec] = {0.f, 0.f, 0.f, 0.f};
+  for (int s = grp; s < nvalid; s += kGroups) {
+    const float f = fast_exp2(ml[2 * s] - M);
+    den = __builtin_fmaf(ml[2 * s + 1], f, den);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(pa + (size_t)s * D);
+#pragma unroll
+    for (int e = 0; e < kVec; ++e) o[e] = __builtin_fmaf(a[e], f, o[e]);
+  }
+#pragma unroll
+  for (int e = 0; e < kVec; ++e) s_red[grp][dv][e] = o[e];
+  s_red[grp][dv][kVec] = den;
+  __syncthreads();
+  if (grp != 0) return;
+  // fixed order over the groups: the result does not depend on timing
+  for (int g = 1; g < kGroups; ++g) {
+#pragma unroll
+    for (int e = 0; e < kVec; ++e) o[e] += s_red[g][dv][e];
+    den += s_red[g][dv][kVec];
+  }
+  const float inv = den > 0.f ? 1.f / den : 0.f;
+  typename Tag::elem_t* dst = static_cast<typename Tag::elem_t*>(p.out) + bh * D + dv * kVec;
+  if constexpr (Tag::kBytes == 4) {
+    *reinterpret_cast<f32x4*>(dst) = f32x4{o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv};
+  } else {
+    float lo[8] = {o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv, 0.f, 0.f, 0.f, 0.f};
+    const u32x4 packed = Tag::pack(lo);
+    *reinterpret_cast<uint2*>(dst) = make_uint2(packed[0], packed[1]);
+  }
+}
+
+constexpr int kWideMergeSplits = 8;   // from this many splits on, one workgroup per (sequence, head) merges
+
 int elems_per_lane(int dtype) { return dtype == MI355_F32 ? 4 : 8; }
 
 #ifndef MI355_DECODE_U
@@ -364,27 +418,29 @@ int make_plan(int B, int Hq, int Hkv, int D, int block_size, int max_context, in
 #define MI355_DECODE_NT 1
 #endif
 
+template <class Tag, int D>
+int launch_merge(const DecodeParams& p, hipStream_t stream) {
+  if constexpr (D >= 16) {
+    if (p.nsplit >= kWideMergeSplits) {
+      hipLaunchKernelGGL((paged_decode_merge_wide_kernel<Tag, D>), dim3((unsigned)((int64_t)p.B * p.Hq)), dim3(256), 0,
+                         stream, p);
+      return check_launch("paged_decode_merge_wide_kernel");
+    }
+  }
+  const int64_t threads = (int64_t)p.B * p.Hq * (D / 4);
+  hipLaunchKernelGGL((paged_decode_merge_kernel<Tag, D>), dim3((unsigned)ceil_div64(threads, 256)), dim3(256), 0,
+                     stream, p);
+  return check_launch("paged_decode_merge_kernel");
+}
+
 template <class Tag, int D, int G>
 int launch_decode(const DecodeParams& p, const DecodePlan& pl, hipStream_t stream) {
   const int64_t grid = (int64_t)p.B * p.nsplit * p.hgroups * p.qchunks;
   hipLaunchKernelGGL((paged_decode_kernel<Tag, D, G, steps_for_group(G), MI355_DECODE_NT != 0>), dim3((unsigned)grid),
                      dim3(pl.nw * kWave), pl.lds_bytes, stream, p);
   if (int rc = check_launch("paged_decode_kernel")) return rc;
-  if (p.nsplit > 1) {
-    const int64_t threads = (int64_t)p.B * p.Hq * (D / 4);
-    hipLaunchKernelGGL((paged_decode_merge_kernel<Tag, D>), dim3((unsigned)ceil_div64(threads, 256)), dim3(256),
-                       0, stream, p);
-    return check_launch("paged_decode_merge_kernel");
-  }
+  if (p.nsplit > 1) return launch_merge<Tag, D>(p, stream);
   return 0;
-}
-
-template <class Tag, int D>
-int launch_merge(const DecodeParams& p, hipStream_t stream) {
-  const int64_t threads = (int64_t)p.B * p.Hq * (D / 4);
-  hipLaunchKernelGGL((paged_decode_merge_kernel<Tag, D>), dim3((unsigned)ceil_div64(threads, 256)), dim3(256), 0,
-                     stream, p);
-  return check_launch("paged_decode_merge_kernel");
 }
 
 // Matrix-core kernel for grouped-query shapes (+ the shared merge kernel when tokens are split).
