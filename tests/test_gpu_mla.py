@@ -30,6 +30,8 @@ def ops():
     # seqs, H, R, P, max_ctx
     (3, 4, 32, 8, 40), (2, 8, 64, 16, 100), (2, 16, 128, 32, 333), (2, 16, 512, 64, 700),
     (1, 20, 256, 64, 50), (1, 128, 512, 64, 130), (5, 3, 32, 24, 17), (3, 16, 128, 24, 450), (2, 9, 256, 8, 300),
+    # more than 16 heads at kv_lora_rank >= 128: 64 heads per workgroup, 16 per wave
+    (2, 32, 512, 64, 700), (2, 48, 128, 32, 333), (1, 100, 256, 24, 300), (3, 17, 512, 64, 95), (1, 64, 512, 64, 3000),
 ])
 def test_mla_decode_kernel(ops, device, shape, dtype):
     seqs, H, R, P, max_ctx = shape
@@ -63,6 +65,29 @@ def test_mla_decode_config4_shape(ops, device):
     out = ops.mla_decode(q.to(device), c_kv.to(device), k_rope.to(device), torch.from_numpy(cos).to(device),
                          torch.from_numpy(sin).to(device), torch.from_numpy(ctx).to(device), S, (128 + 64) ** -0.5)
     np.testing.assert_allclose(out.cpu().numpy(), want, **TOL[torch.bfloat16])
+
+
+def test_mla_many_heads_kernel_matches_16_head_kernel(ops, device, monkeypatch):
+    """128 heads over a split context: the kernel that gives each wave its own 16 heads and the one
+    that runs a workgroup per 16 heads (MI355_MLA_MANY_HEADS=0) agree within tolerance, and both
+    with the oracle on a sample of heads."""
+    rng = np.random.default_rng(12)
+    seqs, H, R, P, S = 3, 128, 512, 64, 2500
+    q = torch.from_numpy(rng.standard_normal((seqs, H, R + P), dtype=np.float32) * 0.3).to(torch.bfloat16)
+    c_kv = torch.from_numpy(rng.standard_normal((seqs, S, R), dtype=np.float32)).to(torch.bfloat16)
+    k_rope = torch.from_numpy(rng.standard_normal((seqs, S, P), dtype=np.float32)).to(torch.bfloat16)
+    ctx = np.array([S, 1, 1777], dtype=np.int32)
+    cos, sin = mo.rope_tables(P, S)
+    args = (q.to(device), c_kv.to(device), k_rope.to(device), torch.from_numpy(cos).to(device),
+            torch.from_numpy(sin).to(device), torch.from_numpy(ctx).to(device), S, 0.07)
+    many = ops.mla_decode(*args).cpu().numpy()
+    monkeypatch.setenv('MI355_MLA_MANY_HEADS', '0')
+    tiled = ops.mla_decode(*args).cpu().numpy()
+    np.testing.assert_allclose(many, tiled, **TOL[torch.bfloat16])
+    heads = [0, 15, 16, 63, 64, 127]
+    want = mo.latent_attention(q[:, heads].float().numpy(), c_kv.float().numpy(), k_rope.float().numpy(), cos, sin,
+                               ctx, 0.07)
+    np.testing.assert_allclose(many[:, heads], want, **TOL[torch.bfloat16])
 
 
 def test_mla_decode_large_shape_properties(ops, device):

@@ -242,6 +242,8 @@ __global__ void __launch_bounds__(256, 2) mla_decode_kernel_w4(const MlaParams p
   constexpr int KSW = (KS + 1) / 2;       // k-steps of the score product per wave
   constexpr int OTW = R / 64;             // 16-dim output tiles per wave
   constexpr int CPR = DK / 8;
+  // 16 B of padding staggers the banks; the conflict-free pitch of the many-heads kernel below
+  // (+32 B) would push two workgroups' tiles past the CU's LDS and measures slower here.
   constexpr int ROWB = DK * 2 + 16;
   constexpr int CCH = R / 8;              // 16-byte chunks of the c_kv part of a row
   constexpr int RSTEP = 256 / CCH;        // rows covered by one pass of the 256 threads over c_kv chunks
@@ -471,6 +473,248 @@ __global__ void __launch_bounds__(256, 2) mla_decode_kernel_w4(const MlaParams p
   }
 }
 
+// Many-heads variant (more than 16 heads, kv_lora_rank >= 128): the four waves share the staged
+// tiles exactly as above, but each wave owns its own 16 heads -- all of their query fragments,
+// scores and latent outputs -- so a cached row is read once per 64 heads instead of once per 16.
+// A wave then holds 72 + 128 registers of fragments and accumulators at R = 512: one workgroup
+// (one wave per SIMD) per CU, with the two-tile register prefetch covering the memory latency.
+// Per 32-token tile a wave issues 2 x KS + R / 16 matrix instructions (68 at R = 512, about a
+// third of the time the tile's 36 KiB take to arrive at the CU's share of HBM bandwidth).
+template <class Tag, int R, int PP>
+__global__ void __launch_bounds__(256) mla_decode_kernel_mh(const MlaParams p) {
+  constexpr int DK = R + PP;
+  constexpr int KS = DK / 32;
+  constexpr int OT = R / 16;              // 16-dim tiles of the latent output
+  constexpr int CPR = DK / 8;
+  // Row pitch = an odd multiple of 32 bytes.  The transposing 8-byte reads of V^T are served 32
+  // lanes = 8 rows x 32 bytes at a time: the rows' 8-bank windows then tile the 64 banks.  The
+  // 16-byte reads of K are served 16 lanes at a time, 8 rows at one chunk and 8 other rows at the
+  // next chunk: with this pitch the first 8 land on the even 4-bank groups, the others on the odd.
+  constexpr int ROWB = DK * 2 + 32;
+  static_assert((ROWB / 32) % 2 == 1, "row pitch must be an odd multiple of 32 bytes");
+  constexpr int CCH = R / 8;              // 16-byte chunks of the c_kv part of a row
+  constexpr int RSTEP = 256 / CCH;        // rows covered by one pass of the 256 threads over c_kv chunks
+  constexpr int NCKV = kTok2 / RSTEP;     // c_kv loads per thread per tile
+  constexpr int RCH = PP / 8;             // chunks of the (padded) k_rope part of a row
+  constexpr int NLOAD = NCKV + 1;         // + one k_rope chunk per thread
+  constexpr int MAXPAIR = 4;              // rope pairs per thread: 4 consecutive dims (P <= 64 -> half <= 32 = 8 x 4)
+  static_assert(kTok2 * RCH <= 256 && CPR == CCH + RCH, "tile staging layout");
+  __shared__ __attribute__((aligned(16))) unsigned char tiles[2][kTok2 * ROWB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+  int bid = blockIdx.x;
+  const int ht = bid % p.n_ht;
+  bid /= p.n_ht;
+  const int sp = bid % p.nsplit;
+  const int row = bid / p.nsplit;
+  const int seq = p.row_seq ? p.row_seq[row] : row;
+  const int ctx = max(0, min(p.ctx[row], p.max_ctx));
+  const int t_begin = sp * p.tps;
+  if (p.nsplit > 1 && t_begin >= ctx) return;
+  const int t_end = min(ctx, t_begin + p.tps);
+  const int head = (ht * 4 + wave) * kHeadTile + c;          // a wave's 16 heads
+  const bool head_ok = head < p.H;
+  const bool wave_live = (ht * 4 + wave) * kHeadTile < p.H;  // else: the wave only helps staging the tiles
+
+  // Query fragments: B operand, lane (c,g) holds Q[head c][32*ks + 8*g .. +8); zero beyond R+P and for padded heads.
+  u32x4 qf[KS];
+  {
+    const char* qrow = static_cast<const char*>(p.q) + ((int64_t)row * p.q_stride_row + (int64_t)head * (R + p.P)) * 2;
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+      const int d = 32 * i + 8 * g;
+      const bool ok = head_ok && (d < R || d - R < p.P);
+      qf[i] = ok ? *reinterpret_cast<const u32x4*>(qrow + d * 2) : u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+  f32x4 o[OT];
+#pragma unroll
+  for (int i = 0; i < OT; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -1.0e30f, l_run = 0.f;
+
+  const char* ckv = static_cast<const char*>(p.ckv) + (int64_t)seq * p.ckv_stride_seq * 2;
+  const char* krope = static_cast<const char*>(p.krope) + (int64_t)seq * p.krope_stride_seq * 2;
+  const int half = p.P >> 1;
+  // rope rotation: thread = (token of the tile, group of 4 consecutive pairs), so that the 8 lanes
+  // of a token read one contiguous 128-byte run of the cos / sin row
+  const int rtok = tid >> 3, rgrp = tid & 7;
+  const bool r_live = 4 * rgrp < half;
+  const int cstride = (int)p.ckv_stride_tok, rstride = (int)p.krope_stride_tok;   // host checks S * stride < 2^30
+
+  // Staging layout: thread -> one fixed c_kv column chunk for rows crow, crow + RSTEP, ... and
+  // one k_rope chunk (row krow, chunk kcol), so the per-load state is one row index.
+  const int ccol = tid % CCH, crow = tid / CCH;
+  const int kcol = tid % RCH, krow = tid / RCH;
+  const bool k_live = kcol * 8 < p.P;
+  const int kcol_ld = k_live ? kcol : 0;
+  u32x4 stage_a[NLOAD], stage_b[NLOAD];
+  float rc[MAXPAIR], rs[MAXPAIR];
+  auto issue_loads = [&](int t0, u32x4 (&stage)[NLOAD]) {
+#pragma unroll
+    for (int i = 0; i < NCKV; ++i) {
+      const int tok = min(t0 + crow + RSTEP * i, t_end - 1);   // rows past the end re-read the last one (masked later)
+      // 32-bit byte offsets from the (wave-uniform) sequence base keep the per-load address state small
+      stage[i] = load16<true>(ckv + (uint32_t)((tok * cstride + ccol * 8) * 2));
+    }
+    // unconditional (address clamped into the row) so the compiler can count outstanding loads
+    // exactly; lanes beyond the rope width are zeroed when the stage is written to LDS
+    const int tok = min(t0 + min(krow, kTok2 - 1), t_end - 1);
+    stage[NCKV] = load16<true>(krope + (uint32_t)((tok * rstride + kcol_ld * 8) * 2));
+  };
+  // cos / sin of the rope pairs this thread rotates in tile t0.  Issued BEFORE the data loads
+  // of the tile after it, so waiting for them never waits for those.
+  auto issue_rope_factors = [&](int t0) {
+    const int pos = min(min(t0 + rtok, t_end - 1), p.table_len - 1);
+    const int col = r_live ? 4 * rgrp : 0;   // unconditional loads; groups beyond the rope width are never rotated
+    const f32x4 cv = *reinterpret_cast<const f32x4*>(p.cos_t + (int64_t)pos * p.P + col);
+    const f32x4 sv = *reinterpret_cast<const f32x4*>(p.sin_t + (int64_t)pos * p.P + col);
+#pragma unroll
+    for (int k = 0; k < MAXPAIR; ++k) {
+      rc[k] = cv[k];
+      rs[k] = sv[k];
+    }
+  };
+
+  const int ntiles = t_end > t_begin ? (t_end - t_begin + kTok2 - 1) / kTok2 : 0;
+
+  // One tile: registers -> LDS, rotate the rope part, refill the same registers with the tile
+  // two steps ahead, then scores / softmax / weighted sum from LDS.
+  auto process = [&](int t, u32x4 (&stage)[NLOAD], auto steady) {
+    const int t0 = t_begin + t * kTok2;
+    unsigned char* tile = tiles[t & 1];
+#pragma unroll
+    for (int i = 0; i < NCKV; ++i)
+      *reinterpret_cast<u32x4*>(tile + (crow + RSTEP * i) * ROWB + ccol * 16) = stage[i];
+    if (krow < kTok2)
+      *reinterpret_cast<u32x4*>(tile + krow * ROWB + R * 2 + kcol * 16) = k_live ? stage[NCKV] : u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+    if (r_live) {   // rotate the rope part of the 32 rows in place: 4 (lo, hi) pairs per thread, 8-byte accesses
+      unsigned char* kr = tile + rtok * ROWB + R * 2 + rgrp * 8;
+      const u32x2 lo2 = *reinterpret_cast<const u32x2*>(kr), hi2 = *reinterpret_cast<const u32x2*>(kr + half * 2);
+      float lo[4], hi[4], nlo[4], nhi[4];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        lo[2 * k] = Tag::to_float((typename Tag::elem_t)(lo2[k] & 0xffffu));
+        lo[2 * k + 1] = Tag::to_float((typename Tag::elem_t)(lo2[k] >> 16));
+        hi[2 * k] = Tag::to_float((typename Tag::elem_t)(hi2[k] & 0xffffu));
+        hi[2 * k + 1] = Tag::to_float((typename Tag::elem_t)(hi2[k] >> 16));
+      }
+#pragma unroll
+      for (int k = 0; k < MAXPAIR; ++k) {
+        nlo[k] = lo[k] * rc[k] - hi[k] * rs[k];
+        nhi[k] = hi[k] * rc[k] + lo[k] * rs[k];
+      }
+      *reinterpret_cast<u32x2*>(kr) = u32x2{Mma16<Tag>::pack2(nlo[0], nlo[1]), Mma16<Tag>::pack2(nlo[2], nlo[3])};
+      *reinterpret_cast<u32x2*>(kr + half * 2) = u32x2{Mma16<Tag>::pack2(nhi[0], nhi[1]), Mma16<Tag>::pack2(nhi[2], nhi[3])};
+    }
+    __syncthreads();
+    if constexpr (decltype(steady)::value) {   // main loop: both refills exist, no branches around the loads
+      issue_rope_factors(t0 + kTok2);
+      issue_loads(t0 + 2 * kTok2, stage);
+    } else {
+      if (t + 1 < ntiles) issue_rope_factors(t0 + kTok2);
+      if (t + 2 < ntiles) issue_loads(t0 + 2 * kTok2, stage);
+    }
+
+    if (!wave_live) return;
+    // S^T[token][head] = K . Q^T for the two 16-token halves of the tile
+    f32x4 st[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < KS; ++i) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(tile + (16 * u + c) * ROWB + (32 * i + 8 * g) * 2);
+        acc = Mma16<Tag>::run(a, qf[i], acc);
+      }
+      st[u] = acc;
+    }
+
+    float s[8], mx = -__builtin_inff();
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float v = (t0 + 16 * u + 4 * g + j < t_end) ? st[u][j] * p.scale_log2e : -__builtin_inff();
+        s[4 * u + j] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float f = fast_exp2(m_run - m_new);
+    m_run = m_new;
+    float ps = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      s[j] = fast_exp2(s[j] - m_new);
+      ps += s[j];
+    }
+    ps += __shfl_xor(ps, 16);
+    ps += __shfl_xor(ps, 32);
+    l_run = l_run * f + ps;
+    if (!__all(f == 1.0f)) {
+#pragma unroll
+      for (int i = 0; i < OT; ++i) o[i] *= f;
+    }
+    // k-slot (g, j): token 4g + j of the first 16 rows for j < 4, token 16 + 4g + (j - 4) for j >= 4
+    const u32x4 pb = {Mma16<Tag>::pack2(s[0], s[1]), Mma16<Tag>::pack2(s[2], s[3]),
+                      Mma16<Tag>::pack2(s[4], s[5]), Mma16<Tag>::pack2(s[6], s[7])};
+    const int qi = c >> 2, pi = c & 3;
+    const unsigned char* vrow = tile + (4 * g + qi) * ROWB + (4 * pi) * 2;
+#pragma unroll
+    for (int i = 0; i < OT; ++i) {
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) s16x4*)(vrow + i * 32));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) s16x4*)(vrow + i * 32 + 16 * ROWB));
+      const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
+      const u32x4 va = {lo2[0], lo2[1], hi2[0], hi2[1]};
+      o[i] = Mma16<Tag>::run(va, pb, o[i]);
+    }
+  };
+
+  // Issue order in the steady state is data(t+2), factors(t+3), data(t+3), ...; the prologue
+  // follows the same order so the compiler's outstanding-load counts agree on both loop edges.
+  int t = 0;
+  if (ntiles >= 4) {
+    issue_loads(t_begin, stage_a);
+    issue_rope_factors(t_begin);
+    issue_loads(t_begin + kTok2, stage_b);
+    do {
+      process(t, stage_a, std::true_type{});
+      process(t + 1, stage_b, std::true_type{});
+      t += 2;
+    } while (t + 3 < ntiles);
+  } else if (ntiles > 0) {
+    issue_loads(t_begin, stage_a);
+    issue_rope_factors(t_begin);
+    if (ntiles > 1) issue_loads(t_begin + kTok2, stage_b);
+  }
+  for (; t < ntiles; t += 2) {   // last one to three tiles
+    process(t, stage_a, std::false_type{});
+    if (t + 1 < ntiles) process(t + 1, stage_b, std::false_type{});
+  }
+
+  if (!head_ok) return;
+  const int d_base = 4 * g;                         // lane holds O[head][d_base + 16*i + j]
+  if (p.nsplit == 1) {
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    float* dst = p.out + ((int64_t)row * p.H + head) * R + d_base;
+#pragma unroll
+    for (int i = 0; i < OT; ++i) *reinterpret_cast<f32x4*>(dst + 16 * i) = o[i] * inv;
+  } else {
+    const int64_t rec = ((int64_t)row * p.H + head) * p.nsplit + sp;
+    float* dst = p.ws_acc + rec * R + d_base;
+#pragma unroll
+    for (int i = 0; i < OT; ++i) *reinterpret_cast<f32x4*>(dst + 16 * i) = o[i];
+    if (g == 0) {
+      p.ws_ml[rec * 2] = m_run;
+      p.ws_ml[rec * 2 + 1] = l_run;
+    }
+  }
+}
+
 template <int R>
 __global__ void __launch_bounds__(256) mla_merge_kernel(const MlaParams p) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -497,6 +741,7 @@ __global__ void __launch_bounds__(256) mla_merge_kernel(const MlaParams p) {
 }
 
 struct MlaPlan {
+  bool many;
   int n_ht, nsplit, tps;
   size_t ws_bytes;
 };
@@ -510,7 +755,8 @@ int mla_plan(int rows, int H, int R, int P, int max_context, int dtype, MlaPlan*
   if (P <= 0 || P > 64 || P % 8) return fail(MI355_EUNSUPPORTED, "mla_decode: rope dim %d (multiple of 8, <= 64)", P);
   if (max_context < 0) return fail(MI355_EINVAL, "mla_decode: max_context %d", max_context);
   MlaPlan pl;
-  pl.n_ht = (H + kHeadTile - 1) / kHeadTile;
+  pl.many = R >= 128 && H > kHeadTile && env_int("MI355_MLA_MANY_HEADS", 1) != 0;   // 64 heads per workgroup
+  pl.n_ht = pl.many ? (H + 4 * kHeadTile - 1) / (4 * kHeadTile) : (H + kHeadTile - 1) / kHeadTile;
   const int ctx = max_context > 0 ? max_context : 1;
   const int64_t base = (int64_t)rows * pl.n_ht;
   // one-wave kernel (R < 128): 8 workgroups per CU.  Four-wave kernel: one workgroup per CU
@@ -530,10 +776,13 @@ int mla_plan(int rows, int H, int R, int P, int max_context, int dtype, MlaPlan*
 }
 
 template <class Tag, int R>
-int launch_r(const MlaParams& p, hipStream_t s) {
+int launch_r(const MlaParams& p, bool many, hipStream_t s) {
   const int64_t grid = (int64_t)p.rows * p.nsplit * p.n_ht;
   if constexpr (R >= 128) {
-    if (p.P <= 32) hipLaunchKernelGGL((mla_decode_kernel_w4<Tag, R, 32>), dim3((unsigned)grid), dim3(256), 0, s, p);
+    if (many) {
+      if (p.P <= 32) hipLaunchKernelGGL((mla_decode_kernel_mh<Tag, R, 32>), dim3((unsigned)grid), dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((mla_decode_kernel_mh<Tag, R, 64>), dim3((unsigned)grid), dim3(256), 0, s, p);
+    } else if (p.P <= 32) hipLaunchKernelGGL((mla_decode_kernel_w4<Tag, R, 32>), dim3((unsigned)grid), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((mla_decode_kernel_w4<Tag, R, 64>), dim3((unsigned)grid), dim3(256), 0, s, p);
   } else {
     if (p.P <= 32) hipLaunchKernelGGL((mla_decode_kernel<Tag, R, 32>), dim3((unsigned)grid), dim3(kWave), 0, s, p);
@@ -549,13 +798,13 @@ int launch_r(const MlaParams& p, hipStream_t s) {
 }
 
 template <class Tag>
-int launch_t(int R, const MlaParams& p, hipStream_t s) {
+int launch_t(int R, const MlaParams& p, bool many, hipStream_t s) {
   switch (R) {
-    case 32: return launch_r<Tag, 32>(p, s);
-    case 64: return launch_r<Tag, 64>(p, s);
-    case 128: return launch_r<Tag, 128>(p, s);
-    case 256: return launch_r<Tag, 256>(p, s);
-    case 512: return launch_r<Tag, 512>(p, s);
+    case 32: return launch_r<Tag, 32>(p, many, s);
+    case 64: return launch_r<Tag, 64>(p, many, s);
+    case 128: return launch_r<Tag, 128>(p, many, s);
+    case 256: return launch_r<Tag, 256>(p, many, s);
+    case 512: return launch_r<Tag, 512>(p, many, s);
   }
   return fail(MI355_EUNSUPPORTED, "mla_decode: kv_lora_rank %d", R);
 }
@@ -622,5 +871,5 @@ extern "C" int mi355_mla_decode(float* out, const void* q, int64_t q_stride_row,
   p.tps = pl.tps;
   p.scale_log2e = scale * 1.4426950408889634f;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  return dtype == MI355_BF16 ? launch_t<BF16>(R, p, s) : launch_t<F16>(R, p, s);
+  return dtype == MI355_BF16 ? launch_t<BF16>(R, p, pl.many, s) : launch_t<F16>(R, p, pl.many, s);
 }
