@@ -28,6 +28,7 @@ from collections import OrderedDict
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -136,13 +137,42 @@ class Request:
         return self.output_token_ids[-1:]
 
 
-@dataclass
 class ScheduledRequest:
-    request: Request
-    tokens: List[int]
-    positions: List[int]
-    is_prefill: bool
-    slot_mapping: List[int]
+    """What one request contributes to a step: its tokens, their positions and KV slots
+    (05_mini_vllm/mini_vllm.py:155-161: request, tokens, positions, is_prefill, slot_mapping).
+
+    The tokens always sit at consecutive positions start .. start + len(tokens) - 1, so the
+    `positions` and `slot_mapping` lists are only materialised when somebody reads them (the
+    engine works from `start` and the request's block table with array arithmetic instead);
+    a block table only ever grows at its end, so a late read gives the values of schedule time.
+    """
+    __slots__ = ('request', 'tokens', 'is_prefill', 'start', 'block_size', '_positions', '_slot_mapping')
+
+    def __init__(self, request: Request, tokens: List[int], positions: Optional[List[int]] = None,
+                 is_prefill: bool = False, slot_mapping: Optional[List[int]] = None,
+                 start: Optional[int] = None, block_size: Optional[int] = None):
+        self.request, self.tokens, self.is_prefill = request, tokens, is_prefill
+        self._positions, self._slot_mapping = positions, slot_mapping
+        self.start = start if start is not None else (positions[0] if positions else 0)
+        self.block_size = block_size
+
+    @property
+    def positions(self) -> List[int]:
+        if self._positions is None:
+            self._positions = list(range(self.start, self.start + len(self.tokens)))
+        return self._positions
+
+    @property
+    def slot_mapping(self) -> List[int]:
+        if self._slot_mapping is None:
+            bs, table = self.block_size, self.request.block_table
+            self._slot_mapping = [table[pos // bs] * bs + pos % bs
+                                  for pos in range(self.start, self.start + len(self.tokens))]
+        return self._slot_mapping
+
+    def __repr__(self) -> str:
+        return (f"ScheduledRequest(request={self.request.request_id!r}, tokens={self.tokens!r}, "
+                f"positions={self.positions!r}, is_prefill={self.is_prefill!r}, slot_mapping={self.slot_mapping!r})")
 
 
 def prompt_block_hashes(token_ids: Sequence[int], block_size: int) -> List[int]:
@@ -233,10 +263,8 @@ class Scheduler:
         return [table[pos // bs] * bs + pos % bs for pos in range(start_pos, start_pos + len(tokens))]
 
     def _emit(self, req: Request, tokens: List[int], start: int, prefill: bool) -> ScheduledRequest:
-        return ScheduledRequest(request=req, tokens=tokens,
-                                positions=list(range(start, start + len(tokens))),
-                                is_prefill=prefill,
-                                slot_mapping=self._compute_slot_mapping(req, tokens, start))
+        return ScheduledRequest(request=req, tokens=tokens, is_prefill=prefill, start=start,
+                                block_size=self.block_size)
 
     def schedule(self) -> List[ScheduledRequest]:
         batch: List[ScheduledRequest] = []
@@ -480,7 +508,7 @@ def build_attn_plan(positions: Sequence[int], seq_lens: Sequence[int], is_prefil
     tok = 0
     for r, (n, prefill) in enumerate(zip(seq_lens, is_prefill)):
         n_q = n if prefill else 1
-        start = positions[tok] if n > 0 else 0
+        start = int(positions[tok]) if n > 0 else 0
         if prefill and (compat or start == 0):
             causal_tok.extend(range(tok, tok + n_q))
             cu.append(cu[-1] + n_q)
@@ -501,13 +529,13 @@ def build_attn_plan(positions: Sequence[int], seq_lens: Sequence[int], is_prefil
         elif use_rows:
             for j in range(n_q):
                 paged_tok.append(tok + j)
-                paged_ctx.append(positions[tok + j] + 1)
+                paged_ctx.append(int(positions[tok + j]) + 1)
                 paged_row.append(table_rows[r])
         else:
             table = block_tables[r]
             for j in range(n_q):
                 paged_tok.append(tok + j)
-                paged_ctx.append(positions[tok + j] + 1)
+                paged_ctx.append(int(positions[tok + j]) + 1)
                 paged_tab.append(table)
         tok += n_q
     total = tok
@@ -1129,16 +1157,27 @@ class MiniVLLM:
         scheduled = self.scheduler.schedule()
         if not scheduled:
             return []
-        tokens: List[int] = []
-        positions: List[int] = []
-        slots: List[int] = []
-        for item in scheduled:
-            tokens += item.tokens
-            positions += item.positions
-            slots += item.slot_mapping
         seq_lens = [len(item.tokens) for item in scheduled]
         prefill_flags = [item.is_prefill for item in scheduled]
         requests = [item.request for item in scheduled]
+        # the step's flattened (token, position, slot) vectors, by array arithmetic per request:
+        # positions are consecutive from item.start, slot = block_table[pos // bs] * bs + pos % bs
+        bs = self.scheduler.block_size
+        tok_parts, pos_parts, slot_parts = [], [], []
+        for item, n in zip(scheduled, seq_lens):
+            req = item.request
+            if item.is_prefill and n > 1:
+                prompt = getattr(req, '_prompt_array', None)
+                if prompt is None:
+                    prompt = req._prompt_array = np.asarray(req.prompt_token_ids, dtype=np.int64)
+                tok_parts.append(prompt[item.start:item.start + n])
+            else:
+                tok_parts.append(np.asarray(item.tokens, dtype=np.int64))
+            pos = np.arange(item.start, item.start + n, dtype=np.int64)
+            pos_parts.append(pos)
+            table = np.asarray(req.block_table, dtype=np.int64)
+            slot_parts.append(table[pos // bs] * bs + pos % bs)
+        host_inputs = np.stack([np.concatenate(tok_parts), np.concatenate(pos_parts), np.concatenate(slot_parts)])
 
         rows = None
         if not self.reference_compat:
@@ -1147,10 +1186,10 @@ class MiniVLLM:
                                                         rows=max(8, self.scheduler.max_num_seqs))
             rows = self._device_tables.sync(requests)
         # one host-to-device copy for the three per-token vectors (the reference makes three, :737-739)
-        step_inputs = torch.tensor([tokens, positions, slots], dtype=torch.long, device=self.device)
+        step_inputs = torch.from_numpy(host_inputs).to(self.device)
         with torch.no_grad():
             logits = self.model(step_inputs[0], step_inputs[1], step_inputs[2], seq_lens, prefill_flags,
-                                positions_host=positions, reference_compat=self.reference_compat,
+                                positions_host=host_inputs[1], reference_compat=self.reference_compat,
                                 device_tables=self._device_tables, table_rows=rows)
         next_tokens = self.sampler.sample(logits, requests)
         self.scheduler.update(scheduled, next_tokens)
