@@ -617,17 +617,36 @@ __global__ void __launch_bounds__(256) mla_decode_kernel_mh(const MlaParams p) {
     }
 
     if (!wave_live) return;
-    // S^T[token][head] = K . Q^T for the two 16-token halves of the tile
+    // S^T[token][head] = K . Q^T for the two 16-token halves of the tile.  The A operands (token
+    // rows from LDS) are fetched kAhead matrix instructions ahead of their use; left to itself
+    // the compiler, short of registers in this kernel, reuses one register quad and waits for
+    // every 16-byte read right before the instruction that consumes it.
     f32x4 st[2];
+    {
+      constexpr int kAhead = 6, NA = 2 * KS;
+      const unsigned char* arow = tile + c * ROWB + 8 * g * 2;
+      auto a_at = [&](int n) __attribute__((always_inline)) {   // n-th operand: half n / KS, k-step n % KS
+        return *reinterpret_cast<const u32x4*>(arow + (n / KS) * 16 * ROWB + (n % KS) * 64);
+      };
+      u32x4 abuf[kAhead];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int n = 0; n < kAhead; ++n) abuf[n] = a_at(n);
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-      for (int i = 0; i < KS; ++i) {
-        const u32x4 a = *reinterpret_cast<const u32x4*>(tile + (16 * u + c) * ROWB + (32 * i + 8 * g) * 2);
-        acc = Mma16<Tag>::run(a, qf[i], acc);
+      for (int n = 0; n < NA; ++n) {
+        const u32x4 a = abuf[n % kAhead];
+        if (n + kAhead < NA) abuf[n % kAhead] = a_at(n + kAhead);
+        acc[n / KS] = Mma16<Tag>::run(a, qf[n % KS], acc[n / KS]);
       }
-      st[u] = acc;
+      __builtin_amdgcn_sched_group_barrier(0x100, kAhead, 0);
+#pragma unroll
+      for (int n = 0; n < NA - kAhead; ++n) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, kAhead, 0);
+      st[0] = acc[0];
+      st[1] = acc[1];
     }
 
     float s[8], mx = -__builtin_inff();
@@ -641,22 +660,30 @@ __global__ void __launch_bounds__(256) mla_decode_kernel_mh(const MlaParams p) {
       }
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
-    const float f = fast_exp2(m_run - m_new);
-    m_run = m_new;
+    // Deferred rescale.  m_run is the reference the exponentials are taken against, not
+    // necessarily the running maximum: it only moves when some head's maximum has outgrown it by
+    // more than kDefer (in log2 units), so weights stay below 2^kDefer and the 128 accumulator
+    // registers of a wave (parked in AccVGPRs) are rescaled on a few tiles per sequence instead
+    // of on every tile in which any of the 16 heads sees a new maximum.  Sums, outputs and the
+    // split records are all relative to the same m_run, so the result is the exact softmax.
+    constexpr float kDefer = 8.f;
+    if (__builtin_amdgcn_ballot_w64(mx > m_run + kDefer) != 0) {
+      const float m_new = fmaxf(m_run, mx);
+      const float f = fast_exp2(m_run - m_new);
+      m_run = m_new;
+      l_run *= f;
+#pragma unroll
+      for (int i = 0; i < OT; ++i) o[i] *= f;
+    }
     float ps = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      s[j] = fast_exp2(s[j] - m_new);
+      s[j] = fast_exp2(s[j] - m_run);
       ps += s[j];
     }
     ps += __shfl_xor(ps, 16);
     ps += __shfl_xor(ps, 32);
-    l_run = l_run * f + ps;
-    if (!__all(f == 1.0f)) {
-#pragma unroll
-      for (int i = 0; i < OT; ++i) o[i] *= f;
-    }
+    l_run += ps;
     // k-slot (g, j): token 4g + j of the first 16 rows for j < 4, token 16 + 4g + (j - 4) for j >= 4
     const u32x4 pb = {Mma16<Tag>::pack2(s[0], s[1]), Mma16<Tag>::pack2(s[2], s[3]),
                       Mma16<Tag>::pack2(s[4], s[5]), Mma16<Tag>::pack2(s[6], s[7])};
