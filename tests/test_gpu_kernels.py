@@ -468,6 +468,42 @@ def test_prefill_varlen_packed(ops, device, dtype):
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('D', [64, 128])
+def test_prefill_scores_that_keep_growing(ops, device, dtype, D):
+    """The kernel moves its softmax reference only when a row's maximum outgrows it by 2^8.  Here
+    the scores of every query rise along the sequence by about 200 log2 units in total (steps and
+    jumps), so the reference moves many times, sometimes in the middle of a tile, and weights taken
+    against an older reference come close to the deferral bound.  Packed and paged entry points."""
+    rng = np.random.default_rng(D)
+    T, Hq, Hkv, BS = 600, 4, 2, 16
+    q = rng.standard_normal((T, Hq, D), dtype=np.float32) * 0.2
+    k = rng.standard_normal((T, Hkv, D), dtype=np.float32) * 0.2
+    v = rng.standard_normal((T, Hkv, D), dtype=np.float32)
+    q[:, :, 0] = 4.0
+    ramp = np.arange(T, dtype=np.float32) * 0.45                      # score ~ scale * 4 * ramp: rises steadily
+    ramp[300:] += 40.0                                                # and jumps by more than the bound at once
+    ramp[437] += 30.0                                                 # a single dominant key inside a tile
+    k[:, :, 0] = (ramp * (D ** 0.5) / 16.0)[:, None]
+    q, k, v = (torch.from_numpy(x).to(dtype) for x in (q, k, v))
+    cu = np.array([0, T], dtype=np.int32)
+    want = orc.varlen_causal_attention(q.float().numpy(), k.float().numpy(), v.float().numpy(), cu, dtype=np.float64)
+    out = ops.prefill_causal(q.to(device), k.to(device), v.to(device), torch.from_numpy(cu).to(device), T)
+    np.testing.assert_allclose(out.float().cpu().numpy(), want, **LOWP_TOL)
+    # the same rows through the paged entry point: first 200 tokens cached, 400 new ones
+    per = (T + BS - 1) // BS
+    bt = rng.permutation(per + 2)[:per].astype(np.int32)
+    kc = torch.zeros((per + 2, Hkv, BS, D), dtype=dtype)
+    vc = torch.zeros((per + 2, Hkv, BS, D), dtype=dtype)
+    for t in range(T):
+        kc[bt[t // BS], :, t % BS] = k[t]
+        vc[bt[t // BS], :, t % BS] = v[t]
+    i32 = lambda x: torch.tensor(x, dtype=torch.int32, device=device)
+    got = ops.paged_prefill(q[200:].to(device), kc.to(device), vc.to(device), i32([bt.tolist()]), i32([0]), i32([400]),
+                            i32([200]), 400, T)
+    np.testing.assert_allclose(got.float().cpu().numpy(), want[200:], **LOWP_TOL)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('shape', [
     # lens, Hq, Hkv, D
     ([128], 8, 8, 64), ([129, 1, 63, 64, 65], 8, 8, 64), ([700], 4, 2, 64), ([300, 257], 8, 1, 128),

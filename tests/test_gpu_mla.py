@@ -90,6 +90,31 @@ def test_mla_many_heads_kernel_matches_16_head_kernel(ops, device, monkeypatch):
     np.testing.assert_allclose(many[:, heads], want, **TOL[torch.bfloat16])
 
 
+@pytest.mark.parametrize('H', [16, 48])
+def test_mla_scores_that_keep_growing(ops, device, H):
+    """Scores that rise along the context by far more than 2^8 in total, with jumps: the many-heads
+    kernel moves its softmax reference several times (it defers the rescale of its accumulators
+    until a maximum outgrows the reference by 2^8), the 16-head kernel rescales on every rise."""
+    rng = np.random.default_rng(H)
+    seqs, R, P, S = 2, 512, 64, 1500
+    q = rng.standard_normal((seqs, H, R + P), dtype=np.float32) * 0.1
+    c_kv = rng.standard_normal((seqs, S, R), dtype=np.float32) * 0.5
+    k_rope = rng.standard_normal((seqs, S, P), dtype=np.float32) * 0.1
+    q[:, :, 0] = 2.0
+    ramp = np.arange(S, dtype=np.float32) * 0.02
+    ramp[700:] += 6.0
+    ramp[1203] += 5.0
+    c_kv[:, :, 0] = ramp[None, :]
+    q, c_kv, k_rope = (torch.from_numpy(x).to(torch.bfloat16) for x in (q, c_kv, k_rope))
+    ctx = np.array([S, 1111], dtype=np.int32)
+    cos, sin = mo.rope_tables(P, S)
+    scale = 1.5      # log2 units: 1.5 * 1.44 * 2 * (0.02 * 1500 + 11) ~ 180 over the context
+    want = mo.latent_attention(q.float().numpy(), c_kv.float().numpy(), k_rope.float().numpy(), cos, sin, ctx, scale)
+    out = ops.mla_decode(q.to(device), c_kv.to(device), k_rope.to(device), torch.from_numpy(cos).to(device),
+                         torch.from_numpy(sin).to(device), torch.from_numpy(ctx).to(device), S, scale)
+    np.testing.assert_allclose(out.cpu().numpy(), want, **TOL[torch.bfloat16])
+
+
 def test_mla_decode_large_shape_properties(ops, device):
     """Config-4 geometry at serving size (64 rows x 4096 tokens, kv_lora_rank 512, rope 64, bf16):
     rows against the float64 oracle, row order does not matter (bit for bit), and a row read

@@ -293,17 +293,31 @@ __global__ void __launch_bounds__(kWaves * kWave, 2) MI355_NO_PACKED_F32 prefill
       pair_values(mx, a, b);
       mx = __builtin_fmaxf(a, b);
     }
-    const float m_new = fmaxf(m_run, mx * p.scale_log2e);
-    const float f = fast_exp2(m_run - m_new);
-    m_run = m_new;
+    // Deferred rescale: m_run is the reference the exponentials are taken against.  It moves (and
+    // the accumulators shrink by f) only when some query's maximum has outgrown it by more than
+    // 2^kDefer; until then weights may exceed 1 (they stay below 2^kDefer), which fp32 sums and
+    // 16-bit weights hold without loss.  Row sums and outputs are relative to the same reference,
+    // so the quotient at the end is the exact softmax.  On ordinary data that is the first tile of
+    // a row and almost never again, instead of every tile in which any of the wave's 32 queries
+    // meets a new maximum.
+    constexpr float kDefer = 8.f;
+    const float mxs = mx * p.scale_log2e;
+    if (__builtin_amdgcn_ballot_w64(mxs > m_run + kDefer) != 0) {
+      const float m_new = fmaxf(m_run, mxs);
+      const float f = fast_exp2(m_run - m_new);
+      m_run = m_new;
+      l_run *= f;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) o[dt] *= f;
+    }
     f32x16 psum16;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
-      st[kt] = st[kt] * p.scale_log2e - m_new;       // packed fma
+      st[kt] = st[kt] * p.scale_log2e - m_run;
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[kt][r] = fast_exp2(st[kt][r]);
     }
-    psum16 = st[0] + st[1];                          // packed adds
+    psum16 = st[0] + st[1];
     float psum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) psum += psum16[r];
@@ -312,11 +326,7 @@ __global__ void __launch_bounds__(kWaves * kWave, 2) MI355_NO_PACKED_F32 prefill
       pair_values(psum, a, b);
       psum = a + b;
     }
-    l_run = l_run * f + psum;
-    if (__builtin_amdgcn_ballot_w64(f != 1.0f) != 0) {                         // the running maximum moved for some query of the wave
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) o[dt] *= f;
-    }
+    l_run += psum;
 
     // ---- O^T += V^T . P^T : k-step s4 covers keys 16*s4 .. 16*s4+15 of the tile.
     // Fragment element j of lane half h is key 16*s4 + 8*(j>>2) + 4*h + (j&3): exactly
