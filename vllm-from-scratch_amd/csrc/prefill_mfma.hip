@@ -262,16 +262,34 @@ __global__ void __launch_bounds__(kWaves * kWave, 2) MI355_NO_PACKED_F32 prefill
     const int kv0 = t * kKT;
     if (kv0 <= qw0 + kQW - 1) {          // else: tile entirely above this wave's diagonal (wave-uniform)
 
-    // ---- S^T = K . Q^T for the two 32-key halves of the tile
+    // ---- S^T = K . Q^T for the two 32-key halves of the tile.  The K operands are fetched
+    // kAhead matrix instructions ahead of their use and the order is pinned: left alone, the
+    // compiler keeps only one or two 16-byte reads in flight and every MFMA waits out most of an
+    // LDS round trip.
     f32x16 st[2];
+    {
+      constexpr int NA = 2 * KS, kAhead = 4;
+      auto a_at = [&](int n) __attribute__((always_inline)) {
+        const int row = 32 * (n / KS) + c, ks = n % KS;
+        return *reinterpret_cast<const u32x4*>(sK + row * ROWB + (((2 * ks + h) ^ kswz(row)) << 4));
+      };
+      u32x4 abuf[kAhead];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      const int row = 32 * kt + c;
+      for (int n = 0; n < kAhead; ++n) abuf[n] = a_at(n);
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const u32x4 a = *reinterpret_cast<const u32x4*>(sK + row * ROWB + (((2 * s + h) ^ kswz(row)) << 4));
-        st[kt] = Mma<Tag>::run(a, qf[s], s == 0 ? f32x16(0.f) : st[kt]);   // first step accumulates onto the constant 0
+      for (int n = 0; n < NA; ++n) {
+        const u32x4 a = abuf[n % kAhead];
+        if (n + kAhead < NA) abuf[n % kAhead] = a_at(n + kAhead);
+        const int kt = n / KS;
+        st[kt] = Mma<Tag>::run(a, qf[n % KS], n % KS == 0 ? f32x16(0.f) : st[kt]);   // first step accumulates onto the constant 0
       }
+      __builtin_amdgcn_sched_group_barrier(0x100, kAhead, 0);
+#pragma unroll
+      for (int n = 0; n < NA - kAhead; ++n) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, kAhead, 0);
     }
     // ---- causal mask, online softmax (the lane's query is column c).  The scale is positive, so
     // the row maximum is taken on the raw scores and scale and shift fold into one fma per score.
