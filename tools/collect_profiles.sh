@@ -3,7 +3,7 @@
 #   tools/collect_profiles.sh <tag>      (writes gpurun_out/<tag>/...)
 # Kernel-trace passes and counter (--pmc) passes are separate rocprofv3 runs.
 set -e
-TAG=${1:-r1e}
+TAG=${1:-r1f}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -38,6 +38,7 @@ timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_
   python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2> "$OUT/pmc_write.log"
 BENCH_MFMA_ONLY=1 tools/pmc_sq.sh "$OUT/pmc_prefill_d128" prefill_mfma tools/bench_prefill.py 4 8192 32 8 128 > "$OUT/pmc_prefill_d128.txt"
 BENCH_MFMA_ONLY=1 tools/pmc_sq.sh "$OUT/pmc_prefill_d64" prefill_mfma tools/bench_prefill.py 2 16384 8 8 64 > "$OUT/pmc_prefill_d64.txt"
+MLA_TARGETS=0 tools/pmc_sq.sh "$OUT/pmc_mla_mh" mla_decode_kernel_mh tools/bench_mla.py 128 128 4096 > "$OUT/pmc_mla_mh.txt"
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_mla_fetch" -o fetch -- \
   python3 tools/bench_mla.py 256 16 4096 > /dev/null 2> "$OUT/pmc_mla_fetch.log"
 
@@ -49,7 +50,9 @@ step secondary benchmarks
   timeout -k 10 200 python3 tools/bench_gqa.py
   timeout -k 10 200 python3 tools/bench_locality.py
   timeout -k 10 200 python3 tools/tune_decode.py c2 256
-  for a in "64 16 4096" "256 16 4096" "128 16 8192"; do MLA_TARGETS=0,0 timeout -k 10 120 python3 tools/bench_mla.py $a | tail -1; done
+  for a in "64 16 4096" "256 16 4096" "128 16 8192" "64 32 4096" "32 64 4096" "128 128 4096"; do MLA_TARGETS=0,0 timeout -k 10 120 python3 tools/bench_mla.py $a | tail -1; done
+  MI355_MLA_MANY_HEADS=0 MLA_TARGETS=0 timeout -k 10 120 python3 tools/bench_mla.py 128 128 4096 | tail -1 | sed 's/^/16 heads per workgroup: /'
+  timeout -k 10 200 python3 tools/bench_small_batch.py
   for a in "16 2048 8 8 64" "2 16384 8 8 64" "16 2048 32 8 128" "4 8192 32 8 128" "64 512 32 8 128"; do BENCH_MFMA_ONLY=1 timeout -k 10 120 python3 tools/bench_prefill.py $a; done
   timeout -k 10 120 python3 tools/bench_prefill.py 16 2048 8 8 64 | grep valu
   for a in "8 1024 3072 32 8 128" "8 1024 3072 8 8 64" "32 256 256 8 8 64" "64 64 1024 8 8 64"; do timeout -k 10 120 python3 tools/bench_paged_prefill.py $a; done

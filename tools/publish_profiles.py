@@ -75,4 +75,16 @@ for shape, label in (('d128', '4 sequences x 8192 tokens, 32/8 heads, D=128, bf1
                    round(c['SQ_LDS_BANK_CONFLICT'] / c['SQ_LDS_IDX_ACTIVE'], 4),
                "waves_per_simd (4 x SQ_WAVE_CYCLES / SIMD cycles)": round(4 * c['SQ_WAVE_CYCLES'] / simd_cycles, 2)},
               open(os.path.join(dst, f'{tag}_pmc_prefill_{shape}.json'), 'w'), indent=1)
+c, n = counters(os.path.join(src, 'pmc_mla_mh/*/*counter_collection.csv'), 'mla_decode_kernel_mh')
+if c:
+    cycles = c['GRBM_GUI_ACTIVE'] / 8
+    json.dump({"kernel": "mla_decode_kernel_mh<BF16,512,64>",
+               "workload": "128 rows x 4096 tokens, 128 heads, kv_lora_rank 512, rope 64 (tools/bench_mla.py 128 128 4096)",
+               "launches": n, "counters (average per launch)": {k: round(v) for k, v in sorted(c.items())},
+               "kernel_cycles (GRBM_GUI_ACTIVE summed over 8 XCDs / 8)": round(cycles),
+               "mfma_busy_fraction": round(c['SQ_VALU_MFMA_BUSY_CYCLES'] / (cycles * 1024), 4),
+               "lds_busy_fraction": round(c['SQ_LDS_IDX_ACTIVE'] / (256 * cycles), 4),
+               "lds_conflict_fraction": round(c['SQ_LDS_BANK_CONFLICT'] / c['SQ_LDS_IDX_ACTIVE'], 4),
+               "wave_wait_fraction (SQ_WAIT_ANY / SQ_WAVE_CYCLES)": round(c['SQ_WAIT_ANY'] / c['SQ_WAVE_CYCLES'], 4)},
+              open(os.path.join(dst, f'{tag}_pmc_mla_many_heads.json'), 'w'), indent=1)
 print(sorted(f for f in os.listdir(dst) if f.startswith(tag)))
