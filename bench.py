@@ -120,6 +120,12 @@ def main():
     ap.add_argument('--gather-every', type=int, default=4,
                     help='steps whose sampled ids share one all-gather (N > 1); every id is exchanged inside the timed region')
     args = ap.parse_args()
+    # Keep stdout for the one JSON line: whatever libraries print on file descriptor 1 while the
+    # job runs (the collective library prints a version banner there when its communicator comes
+    # up) goes to stderr instead.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -239,7 +245,8 @@ def main():
             line["roofline"]["traffic_source"] = os.path.relpath(traffic_files[-1], ROOT)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, inp)
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if native is not None:
         torch.cuda.synchronize()
         native.close()
