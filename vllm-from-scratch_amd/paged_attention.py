@@ -132,10 +132,9 @@ def paged_attention_decode(
     block_table; query heads g*kv_h .. g*(kv_h+1)-1 read kv head kv_h
     (01_paged_attention/paged_attention.py:67-101).  Returns a new [num_q_heads, head_dim]
     tensor of query's dtype on query's device."""
-    table = _as_int_list(block_table)
     if seq_len <= 0:
         raise RuntimeError("stack expects a non-empty TensorList")  # what the reference raises
-    if (seq_len + block_size - 1) // block_size > len(table):
+    if (seq_len + block_size - 1) // block_size > len(block_table):
         raise IndexError("list index out of range")
     if tuple(query.shape) != (num_q_heads, head_dim):
         raise ValueError(f"query must be [{num_q_heads}, {head_dim}], got {tuple(query.shape)}")
@@ -145,8 +144,14 @@ def paged_attention_decode(
     dev = _compute_device(query, kv_cache)
     cache = kv_cache.to(device=dev, dtype=query.dtype)
     q = query.to(dev).unsqueeze(0)
-    tables = torch.tensor([table], dtype=torch.int32, device=dev)
-    lens = torch.tensor([seq_len], dtype=torch.int32, device=dev)
+    if isinstance(block_table, torch.Tensor) and block_table.is_cuda:
+        # a table that already lives on the device is used where it is (no read-back)
+        tables = block_table.to(device=dev, dtype=torch.int32).reshape(1, -1)
+        lens = torch.tensor([seq_len], dtype=torch.int32, device=dev)
+    else:
+        # block table and context length travel in one host-to-device copy
+        packed = torch.tensor(_as_int_list(block_table) + [seq_len], dtype=torch.int32, device=dev)
+        tables, lens = packed[:-1].unsqueeze(0), packed[-1:]
     out = ops.paged_decode(q, cache[0], cache[1], tables, lens, seq_len, layout='NHSD')
     return out[0].to(query.device)
 
