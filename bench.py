@@ -237,7 +237,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "kernel": "mi355_paged_decode (paged_decode_kernel + split merge)",
                          "algorithmic_bytes_per_launch": abytes,
-                         "avg_launch_ms": round(avg_ms, 5),
+                         "avg_launch_ms": round(avg_ms, 5), "launches_timed": len(kernel_ms),
                          "p10_ms": round(kernel_ms[len(kernel_ms) // 10], 5),
                          "p50_ms": round(kernel_ms[len(kernel_ms) // 2], 5),
                          "p90_ms": round(kernel_ms[(len(kernel_ms) * 9) // 10], 5)},
