@@ -114,11 +114,14 @@ def test_decode_only_path_reproduces_the_general_scheduler():
     """schedule_decode_only / update_decode_only leave requests, block tables and the allocator
     (free-list order, refcounts) exactly as schedule / update do, step for step -- including runs
     where blocks run short (the path declines and the general scheduler skips requests), requests
-    finish by EOS mid-batch, and new prompts keep arriving behind running decodes."""
+    finish by EOS mid-batch, and requests wait for a sequence slot behind running decodes."""
     cases = [dict(num_blocks=64, nreq=5, prompt_lens=[3, 9, 4], max_new=[9, 5, 14]),
              dict(num_blocks=9, nreq=4, prompt_lens=[7, 5], max_new=[3, 12]),          # temporary block shortage
              dict(num_blocks=64, nreq=9, prompt_lens=[2, 11, 6], max_new=[8, 3], eos_every=7),
-             dict(num_blocks=40, nreq=8, prompt_lens=[30, 3], max_new=[6], chunked=False)]
+             dict(num_blocks=40, nreq=8, prompt_lens=[30, 3], max_new=[6], chunked=False),
+             # more requests than sequence slots: the path also serves steps in which requests wait
+             # for a slot (nobody can be admitted), and must decline the moment one frees
+             dict(num_blocks=64, nreq=14, prompt_lens=[5, 2, 9], max_new=[4, 11, 7], eos_every=5)]
     for kw in cases:
         slow, none_served = _drive(False, **kw)
         fast, served = _drive(True, **kw)

@@ -196,6 +196,25 @@ def test_engine_lookahead_decode_equals_step_by_step(device, dtype):
     assert sorted(r.request_id for r in ahead.scheduler.finished) == sorted(r.request_id for r in eager.scheduler.finished)
 
 
+def test_engine_more_requests_than_slots_equals_eager(device):
+    """Continuous batching with a waiting queue: captured decode steps (and steps issued ahead) run
+    while every sequence slot is taken, the general path takes over the moment a slot frees.  Every
+    request gets exactly the tokens the eager engine gives it (greedy; a 12-id vocabulary makes
+    end-of-sequence ids frequent, which is when the lookahead engine admits a waiting request one
+    step later than the step-by-step engines)."""
+    import mini_vllm as mv
+    rng = np.random.default_rng(31)
+    prompts = [[int(t) for t in rng.integers(1, 12, size=int(n))] for n in rng.integers(2, 30, size=40)]
+    max_new = [int(n) for n in rng.integers(3, 40, size=40)]
+    eager, out_e, _ = _run(mv, False, torch.float32, prompts, max_new, vocab=12)
+    plain, out_p, steps_p = _run(mv, True, torch.float32, prompts, max_new, vocab=12, decode_lookahead=False)
+    ahead, out_a, _ = _run(mv, True, torch.float32, prompts, max_new, vocab=12, decode_lookahead=True)
+    assert out_p == out_e and out_a == out_e
+    assert len(plain._graphs) >= 1 and plain._launches > 10          # the captured path did serve steps
+    assert ahead._launches > 10 and ahead._inflight is None
+    assert ahead.allocator.num_free == 256 and plain.allocator.num_free == 256
+
+
 def test_engine_lookahead_accepts_requests_mid_run(device):
     """A request added while a speculative step is in flight joins through the general path and
     every request still gets the tokens it gets when run alone (greedy)."""

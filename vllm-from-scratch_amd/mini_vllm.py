@@ -338,14 +338,19 @@ class Scheduler:
 
     def schedule_decode_only(self) -> Optional[List[Request]]:
         """The outcome of schedule() for the steady state of generation, without building
-        ScheduledRequest objects: nothing waiting, every running request past its prompt, and
-        enough free blocks that no request would be skipped.  Returns the requests in batch
+        ScheduledRequest objects: nothing waiting (or no sequence slot left for a waiting
+        request), every running request past its prompt, and enough free blocks that no request
+        would be skipped.  Returns the requests in batch
         order (each feeds its last token at position num_computed_tokens) after growing their
         block tables exactly as schedule() would, or None -- having changed nothing -- when any
         precondition fails and schedule() must decide."""
         running = self.running
         n = len(running)
-        if self.waiting or n == 0 or n > self.max_num_seqs or n > self.max_num_batched_tokens:
+        if n == 0 or n > self.max_num_seqs or n > self.max_num_batched_tokens:
+            return None
+        # waiting requests are only admitted while there is room for another sequence; with every
+        # slot taken by a running request schedule() would leave them waiting
+        if self.waiting and n < self.max_num_seqs:
             return None
         bs = self.block_size
         short = 0
@@ -1094,13 +1099,15 @@ class MiniVLLM:
         fact: its row of the step issued here is wasted and its result dropped.  None when the
         scheduler would not produce a pure-decode step of exactly these requests."""
         sch = self.scheduler
-        if sch.waiting:
-            return None
         live = [(j, r) for j, r in enumerate(cur.batch) if not r.is_finished]
         if len(live) != len(sch.running):
             return None
         ahead = [(j, r) for j, r in live if len(r.output_token_ids) + 1 < r.max_new_tokens]
         if not ahead or len(ahead) > sch.max_num_seqs or len(ahead) > sch.max_num_batched_tokens:
+            return None
+        # a waiting request joins as soon as a sequence slot frees: only look ahead past it while
+        # every slot stays taken (nobody reaches its length limit with the step in flight)
+        if sch.waiting and len(ahead) < sch.max_num_seqs:
             return None
         bs = sch.block_size
         short = 0
