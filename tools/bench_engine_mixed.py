@@ -16,18 +16,14 @@ plens = rng.integers(64, 513, size=nreq)
 news = rng.integers(16, 65, size=nreq)
 
 
-def build():
-    torch.manual_seed(0)
-    eng = mv.MiniVLLM(vocab_size=32000, hidden_size=512, num_layers=4, num_heads=8, intermediate_size=1536,
-                      num_kv_blocks=nseq * 40, block_size=16, max_num_seqs=nseq, max_num_batched_tokens=budget,
-                      device='cuda', dtype=torch.bfloat16)
-    for p, n in zip(plens, news):
+torch.manual_seed(0)
+eng = mv.MiniVLLM(vocab_size=32000, hidden_size=512, num_layers=4, num_heads=8, intermediate_size=1536,
+                  num_kv_blocks=nseq * 40, block_size=16, max_num_seqs=nseq, max_num_batched_tokens=budget,
+                  device='cuda', dtype=torch.bfloat16)
+
+for rep in range(2):                       # one engine serves both passes: the first warms kernels,
+    for p, n in zip(plens, news):          # GEMM plans and the captured decode graphs, the second is timed
         eng.add_request([int(t) for t in rng.integers(1, 32000, size=int(p))], max_new_tokens=int(n), temperature=0.0)
-    return eng
-
-
-for rep in range(2):                       # first pass warms kernels, GEMM plans and graphs
-    eng = build()
     steps = fast = 0
     out_tokens = 0
     torch.cuda.synchronize()

@@ -35,6 +35,23 @@ import torch.nn.functional as F
 
 from mi355_paged import ops
 
+_NUMPY_DTYPE = {torch.int64: np.int64, torch.int32: np.int32, torch.float32: np.float32, torch.bool: np.bool_}
+
+
+def _upload(values, dtype: torch.dtype, device) -> torch.Tensor:
+    """Small host data (lists, arrays) -> a device tensor without stalling the device.
+
+    torch.tensor(values, device=...) copies from pageable memory, which the runtime does
+    synchronously: the call returns only after everything queued on the stream before it has
+    run, so a step that builds a dozen small index tensors alternates host and device work
+    instead of overlapping them.  Staged through pinned memory (recycled by torch's host
+    allocator once the copy has executed) the copy is asynchronous."""
+    t = torch.from_numpy(np.ascontiguousarray(np.asarray(values, dtype=_NUMPY_DTYPE[dtype])))
+    device = torch.device(device)
+    if device.type != 'cuda':
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
 
 # ---------------------------------------------------------------------------
 # KV block allocator (host integers)
@@ -443,7 +460,7 @@ class DeviceBlockTables:
                 self._uploaded[req.request_id] = len(table)
             out.append(row)
         if vals:
-            packed = torch.tensor([r_idx, c_idx, vals], dtype=torch.int64, device=self.device)
+            packed = _upload([r_idx, c_idx, vals], torch.int64, self.device)
             self.tables[packed[0], packed[1]] = packed[2].to(torch.int32)
         return out
 
@@ -455,7 +472,7 @@ class DeviceBlockTables:
 
     def gather(self, rows: Sequence[int]) -> torch.Tensor:
         """[len(rows), width] int32 block tables for the given rows (device gather)."""
-        return self.tables.index_select(0, torch.tensor(rows, dtype=torch.int64, device=self.device))
+        return self.tables.index_select(0, _upload(rows, torch.int64, self.device))
 
 
 @dataclass
@@ -548,14 +565,14 @@ def build_attn_plan(positions: Sequence[int], seq_lens: Sequence[int], is_prefil
     def idx(lst):
         if len(lst) == total:
             return None
-        return torch.tensor(lst, dtype=torch.int64, device=device)
+        return _upload(lst, torch.int64, device)
 
     plan = AttnPlan(total_tokens=total, causal_index=None, cu_seqlens=None, causal_tokens=len(causal_tok),
                     max_causal_len=max_len, paged_index=None, paged_tables=None, paged_context=None,
                     paged_rows=len(paged_tok), max_context=max(paged_ctx) if paged_ctx else 0)
     if causal_tok:
         plan.causal_index = idx(causal_tok)
-        plan.cu_seqlens = torch.tensor(cu, dtype=torch.int32, device=device)
+        plan.cu_seqlens = _upload(cu, torch.int32, device)
     if paged_tok:
         plan.paged_index = idx(paged_tok)
         if paged_row:
@@ -563,19 +580,18 @@ def build_attn_plan(positions: Sequence[int], seq_lens: Sequence[int], is_prefil
         else:
             width = max(len(t) for t in paged_tab)
             rows = [list(t) + [0] * (width - len(t)) for t in paged_tab]
-            plan.paged_tables = torch.tensor(rows, dtype=torch.int32, device=device)
-        plan.paged_context = torch.tensor(paged_ctx, dtype=torch.int32, device=device)
+            plan.paged_tables = _upload(rows, torch.int32, device)
+        plan.paged_context = _upload(paged_ctx, torch.int32, device)
     if app_meta[0]:
         plan.append_tokens = sum(app_meta[1])
         plan.max_append_len = max(app_meta[1])
         plan.max_append_context = max(p0 + n for p0, n in zip(app_meta[2], app_meta[1]))
-        plan.append_meta = torch.tensor(app_meta, dtype=torch.int32, device=device)
+        plan.append_meta = _upload(app_meta, torch.int32, device)
         if app_row:
             plan.append_tables = device_tables.gather(app_row)
         else:
             width = max(len(t) for t in app_tab)
-            plan.append_tables = torch.tensor([list(t) + [0] * (width - len(t)) for t in app_tab],
-                                              dtype=torch.int32, device=device)
+            plan.append_tables = _upload([list(t) + [0] * (width - len(t)) for t in app_tab], torch.int32, device)
     return plan
 
 
@@ -969,14 +985,14 @@ class Sampler:
             top_k = [int(getattr(r, 'top_k', 0) or 0) for r in requests]
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
             drawn = ops.sample_topk_topp(
-                rows, torch.tensor([t if t != 0.0 else 1.0 for t in temps], dtype=torch.float32, device=dev),
-                torch.tensor(top_p, dtype=torch.float32, device=dev) if any(p < 1.0 for p in top_p) else None,
-                torch.tensor(top_k, dtype=torch.int32, device=dev) if any(k > 0 for k in top_k) else None,
+                rows, _upload([t if t != 0.0 else 1.0 for t in temps], torch.float32, dev),
+                _upload(top_p, torch.float32, dev) if any(p < 1.0 for p in top_p) else None,
+                _upload(top_k, torch.int32, dev) if any(k > 0 for k in top_k) else None,
                 seed=seed, out=out if picked is None else None)
             if picked is None:
                 picked = drawn
             else:
-                picked = torch.where(torch.tensor(greedy, device=dev), picked[:n], drawn[:n])
+                picked = torch.where(_upload(greedy, torch.bool, dev), picked[:n], drawn[:n])
                 if out is not None:
                     out[:n].copy_(picked)
         return picked[:n]
@@ -1193,7 +1209,7 @@ class MiniVLLM:
                                                         rows=max(8, self.scheduler.max_num_seqs))
             rows = self._device_tables.sync(requests)
         # one host-to-device copy for the three per-token vectors (the reference makes three, :737-739)
-        step_inputs = torch.from_numpy(host_inputs).to(self.device)
+        step_inputs = _upload(host_inputs, torch.int64, self.device)
         with torch.no_grad():
             logits = self.model(step_inputs[0], step_inputs[1], step_inputs[2], seq_lens, prefill_flags,
                                 positions_host=host_inputs[1], reference_compat=self.reference_compat,
