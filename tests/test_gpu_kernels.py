@@ -642,6 +642,24 @@ def test_sampling_filters_match_oracle(ops, device, vocab):
         assert abs(probs[b].sum() - 1.0) < 1e-4
 
 
+def test_sampling_top_k_without_top_p_on_a_peaked_row(ops, device):
+    """top_p = 1 means "no nucleus cut" (05_mini_vllm/mini_vllm.py:619), also when a top-k limit is set:
+    on a peaked row the mass above the small entries rounds to 1.0f, and a `mass < top_p` test
+    would drop them although fewer than k entries precede them."""
+    rng = np.random.default_rng(77)
+    vocab = 257
+    logits = (rng.standard_normal((3, vocab)) * 8).astype(np.float32)
+    temps, top_ps, top_ks = [0.7, 0.7, 0.7], [1.0, 1.0, 1.0], [1000, vocab, 200]
+    _, probs = ops.sample_topk_topp(torch.from_numpy(logits).to(device), torch.tensor(temps, device=device),
+                                    torch.tensor(top_ps, device=device),
+                                    torch.tensor(top_ks, dtype=torch.int32, device=device), seed=5, return_probs=True)
+    probs = probs.cpu().numpy()
+    for b in range(3):
+        want, kept = orc.nucleus_probs(logits[b], temps[b], top_ps[b], top_ks[b])
+        assert int((probs[b] > 0).sum()) == min(top_ks[b], vocab) == int(kept.sum())
+        np.testing.assert_allclose(probs[b], want, rtol=2e-4, atol=1e-30)
+
+
 @pytest.mark.parametrize('vocab', [64, 3000, 32000, 40000])
 def test_sampling_ties_at_the_cut_keep_lowest_indices(ops, device, vocab):
     """Rows built so that the cut falls inside a run of EQUAL probabilities: of the tied tokens the

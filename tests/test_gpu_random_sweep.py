@@ -1,0 +1,202 @@
+"""Seeded random shape sweeps of the attention kernels against the numpy oracle.
+
+The hand-picked cases in test_gpu_kernels.py aim at known borders (tile edges, split paths,
+odd block sizes).  These sweeps draw every dimension at random -- batch, head grouping,
+head_dim, block size, context lengths (zero included), dtype, cache layout -- so that
+combinations nobody thought of still meet the oracle.  Each draw is small enough for the
+oracle to finish in well under a second; seeds are fixed, so a failure names its case.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import paged_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+LOWP_TOL = dict(atol=1e-2, rtol=1.6e-2)
+F32_TOL = dict(atol=1e-5, rtol=1e-5)
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from mi355_paged import ops as _ops
+    return _ops
+
+
+def _rounded(a, dtype):
+    return a if dtype == torch.float32 else torch.from_numpy(a).to(dtype).float().numpy()
+
+
+def _head_grouping(rng):
+    hkv = int(rng.choice([1, 2, 3, 4, 8]))
+    group = int(rng.choice([1, 1, 2, 3, 4, 5, 8, 16]))
+    return hkv * group, hkv
+
+
+@pytest.mark.parametrize('seed', range(48))
+def test_decode_random_shapes(ops, device, seed):
+    rng = np.random.default_rng(1000 + seed)
+    dtype = DTYPES[seed % 3]
+    layout = 'NHSD' if (seed // 3) % 2 == 0 else 'NSHD'
+    Hq, Hkv = _head_grouping(rng)
+    D = int(rng.choice([16, 32, 64, 64, 128, 128, 256]))
+    BS = int(rng.choice([1, 2, 3, 4, 8, 16, 16, 32, 64]))
+    B = int(rng.integers(1, 9))
+    max_ctx = int(rng.choice([1, 7, 33, 100, 260, 700, 1500, 4200] if B * Hq * D <= 4096 else [1, 7, 33, 100, 260, 700]))
+    ctx = [int(c) for c in rng.integers(0, max_ctx + 1, size=B)]
+    ctx[int(rng.integers(0, B))] = max_ctx
+    per = (max_ctx + BS - 1) // BS
+    NB = B * per + 3
+    bt = rng.permutation(NB)[:B * per].reshape(B, per).astype(np.int32)
+    cache = _rounded(rng.standard_normal((2, NB, Hkv, BS, D), dtype=np.float32), dtype)
+    q = _rounded(rng.standard_normal((B, Hq, D), dtype=np.float32), dtype)
+
+    tc = torch.from_numpy(cache).to(device=device, dtype=dtype)
+    if layout == 'NSHD':
+        tc = tc.permute(0, 1, 3, 2, 4).contiguous()
+    out = ops.paged_decode(torch.from_numpy(q).to(device=device, dtype=dtype), tc[0], tc[1],
+                           torch.from_numpy(bt).to(device), torch.tensor(ctx, dtype=torch.int32, device=device),
+                           max_ctx, layout=layout)
+    got = out.float().cpu().numpy()
+    tol = F32_TOL if dtype == torch.float32 else LOWP_TOL
+    for b in range(B):
+        if ctx[b] == 0:
+            assert (got[b] == 0).all(), (b, 'an empty context yields zeros')
+            continue
+        want = orc.paged_decode(q[b], cache[0], cache[1], bt[b].tolist(), ctx[b], BS, dtype=np.float64)
+        np.testing.assert_allclose(got[b], want, err_msg=f'row {b} ctx {ctx[b]} {Hq}/{Hkv} D{D} BS{BS} {layout}', **tol)
+
+
+@pytest.mark.parametrize('seed', range(24))
+def test_paged_prefill_random_segments(ops, device, seed):
+    """Chunks of new tokens behind cached prefixes of random length; both the decode-shaped
+    kernel (short chunks) and the flash-attention kernel in paged mode (48 tokens and up)."""
+    rng = np.random.default_rng(2000 + seed)
+    dtype = [torch.bfloat16, torch.float16][seed % 2]
+    layout = 'NHSD' if (seed // 2) % 2 == 0 else 'NSHD'
+    Hq, Hkv = _head_grouping(rng)
+    D = int(rng.choice([64, 128]))
+    BS = int(rng.choice([1, 3, 8, 16, 16, 32, 128]))
+    nseg = int(rng.integers(1, 5))
+    segs = []
+    for _ in range(nseg):
+        n = int(rng.choice([1, 2, 15, 40, 47, 48, 49, 100, 130, 260]))
+        p0 = int(rng.choice([0, 1, 15, 16, 31, 100, 127, 128, 500]))
+        segs.append((p0, n))
+    max_ctx = max(p0 + n for p0, n in segs)
+    per = (max_ctx + BS - 1) // BS
+    NB = nseg * per + 2
+    bt = rng.permutation(NB)[:nseg * per].reshape(nseg, per).astype(np.int32)
+    cache = torch.from_numpy(rng.standard_normal((2, NB, Hkv, BS, D), dtype=np.float32)).to(dtype)
+    gap = int(rng.integers(0, 3))                                     # rows that belong to no segment
+    T = sum(n for _, n in segs) + gap * (nseg + 1)
+    q = torch.from_numpy(rng.standard_normal((T, Hq, D), dtype=np.float32)).to(dtype)
+    starts, q0 = [], gap
+    for _, n in segs:
+        starts.append(q0)
+        q0 += n + gap
+    tc = cache.to(device)
+    if layout == 'NSHD':
+        tc = tc.permute(0, 1, 3, 2, 4).contiguous()
+    out = torch.full((T, Hq, D), 7.0, dtype=dtype, device=device)
+    ops.paged_prefill(q.to(device), tc[0], tc[1], torch.from_numpy(bt).to(device),
+                      torch.tensor(starts, dtype=torch.int32, device=device),
+                      torch.tensor([n for _, n in segs], dtype=torch.int32, device=device),
+                      torch.tensor([p0 for p0, _ in segs], dtype=torch.int32, device=device),
+                      max(n for _, n in segs), max_ctx, layout=layout, out=out)
+    got = out.float().cpu().numpy()
+    qn, cn = q.float().numpy(), cache.float().numpy()
+    owned = np.zeros(T, dtype=bool)
+    for s, (p0, n) in enumerate(segs):
+        rows = sorted(set([0, n - 1] + [int(j) for j in rng.integers(0, n, size=min(n, 6))]))
+        owned[starts[s]:starts[s] + n] = True
+        for j in rows:
+            want = orc.paged_decode(qn[starts[s] + j], cn[0], cn[1], bt[s].tolist(), p0 + j + 1, BS, dtype=np.float64)
+            np.testing.assert_allclose(got[starts[s] + j], want,
+                                       err_msg=f'segment {s} {segs[s]} token {j} {Hq}/{Hkv} D{D} BS{BS} {layout}', **LOWP_TOL)
+    assert (got[~owned] == 7.0).all()
+    assert np.isfinite(got[owned]).all()
+
+
+@pytest.mark.parametrize('seed', range(24))
+def test_prefill_causal_random_packing(ops, device, seed):
+    """Packed variable-length prompts: fp32 runs the VALU kernel, 16-bit at head_dim 64 / 128 the
+    matrix-core kernel, 16-bit at other head dims the VALU kernel again."""
+    rng = np.random.default_rng(3000 + seed)
+    dtype = DTYPES[seed % 3]
+    Hq, Hkv = _head_grouping(rng)
+    D = int(rng.choice([32, 64, 64, 128, 128, 256]))
+    nseq = int(rng.integers(1, 6))
+    lens = [int(rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 200, 257, 400])) for _ in range(nseq)]
+    if Hq * D > 2048:
+        lens = [min(n, 130) for n in lens]
+    T = sum(lens)
+    q = torch.from_numpy(rng.standard_normal((T, Hq, D), dtype=np.float32)).to(dtype)
+    k = torch.from_numpy(rng.standard_normal((T, Hkv, D), dtype=np.float32)).to(dtype)
+    v = torch.from_numpy(rng.standard_normal((T, Hkv, D), dtype=np.float32)).to(dtype)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    want = orc.varlen_causal_attention(q.float().numpy(), k.float().numpy(), v.float().numpy(), cu, dtype=np.float64)
+    out = ops.prefill_causal(q.to(device), k.to(device), v.to(device), torch.from_numpy(cu).to(device), max(lens))
+    np.testing.assert_allclose(out.float().cpu().numpy(), want, err_msg=f'lens {lens} {Hq}/{Hkv} D{D}',
+                               **(F32_TOL if dtype == torch.float32 else LOWP_TOL))
+
+
+MLA_TOL = {torch.bfloat16: dict(atol=1e-2, rtol=1.6e-2), torch.float16: dict(atol=2e-3, rtol=4e-3)}
+
+
+@pytest.mark.parametrize('seed', range(24))
+def test_mla_decode_random_shapes(ops, device, seed):
+    """Latent-KV attention: kv_lora_rank, rope width, head count (both the 16-heads-per-workgroup
+    and the 64-heads-per-workgroup kernels) and ragged contexts drawn at random."""
+    from oracle import mla_oracle as mo
+    rng = np.random.default_rng(4000 + seed)
+    dtype = [torch.bfloat16, torch.float16][seed % 2]
+    R = int(rng.choice([32, 64, 128, 256, 512]))
+    P = int(rng.choice([8, 16, 24, 32, 64]))
+    H = int(rng.choice([1, 3, 8, 16, 17, 32, 40, 64, 65, 128]))
+    seqs = int(rng.integers(1, 5))
+    max_ctx = int(rng.choice([1, 15, 64, 65, 200, 513, 1100] if H * R <= 16384 else [1, 15, 64, 65, 200]))
+    S = max_ctx + int(rng.integers(0, 4))                             # cache rows beyond the longest context
+    q = torch.from_numpy(rng.standard_normal((seqs, H, R + P), dtype=np.float32) * 0.5).to(dtype)
+    c_kv = torch.from_numpy(rng.standard_normal((seqs, S, R), dtype=np.float32)).to(dtype)
+    k_rope = torch.from_numpy(rng.standard_normal((seqs, S, P), dtype=np.float32)).to(dtype)
+    ctx = rng.integers(1, max_ctx + 1, size=seqs).astype(np.int32)
+    ctx[int(rng.integers(0, seqs))] = max_ctx
+    cos, sin = mo.rope_tables(P, S + 1)
+    scale = float(rng.choice([0.05, 0.11, (R // 4 + P) ** -0.5]))
+    want = mo.latent_attention(q.float().numpy(), c_kv.float().numpy(), k_rope.float().numpy(), cos, sin, ctx, scale)
+    out = ops.mla_decode(q.to(device), c_kv.to(device), k_rope.to(device), torch.from_numpy(cos).to(device),
+                         torch.from_numpy(sin).to(device), torch.from_numpy(ctx).to(device), max_ctx, scale)
+    np.testing.assert_allclose(out.cpu().numpy(), want, err_msg=f'H{H} R{R} P{P} ctx {ctx.tolist()}', **MLA_TOL[dtype])
+
+
+@pytest.mark.parametrize('seed', range(40))
+def test_sampler_random_rows(ops, device, seed):
+    """Greedy ids exact and the kept set / renormalised probabilities of the temperature, top-p and
+    top-k filters against the sorting oracle, for random vocabulary sizes, row counts and settings."""
+    rng = np.random.default_rng(5000 + seed)
+    vocab = int(rng.choice([2, 17, 257, 1024, 4099, 32000, 32769, 50257, 100003]))
+    B = int(rng.integers(1, 7))
+    spread = float(rng.choice([0.5, 3.0, 8.0]))
+    logits = (rng.standard_normal((B, vocab)) * spread).astype(np.float32)
+    dev_logits = torch.from_numpy(logits).to(device)
+    assert ops.sample_argmax(dev_logits).cpu().tolist() == logits.argmax(axis=1).tolist()
+    temps = [float(t) for t in rng.choice([0.3, 0.7, 1.0, 1.5], size=B)]
+    top_ps = [float(p) for p in rng.choice([0.2, 0.5, 0.9, 0.99, 1.0], size=B)]
+    top_ks = [int(k) for k in rng.choice([0, 0, 1, 5, 50, 1000], size=B)]
+    ids, probs = ops.sample_topk_topp(dev_logits, torch.tensor(temps, device=device), torch.tensor(top_ps, device=device),
+                                      torch.tensor(top_ks, dtype=torch.int32, device=device), seed=seed, return_probs=True)
+    probs = probs.cpu().numpy()
+    for b in range(B):
+        want, kept = orc.nucleus_probs(logits[b], temps[b], top_ps[b], top_ks[b])
+        got_kept = probs[b] > 0
+        # only the token whose running mass lands within float rounding of top_p may differ; entries whose
+        # probability underflows float32 (peaked rows at low temperature) are "kept" with probability 0
+        diff = np.nonzero((got_kept != kept) & (np.maximum(want, probs[b]) > 1e-30))[0]
+        assert len(diff) <= 1, f'row {b} vocab {vocab} T{temps[b]} p{top_ps[b]} k{top_ks[b]}: kept sets differ at {diff}'
+        if len(diff) == 0:
+            np.testing.assert_allclose(probs[b], want, rtol=2e-4, atol=1e-7)
+        assert got_kept[int(ids[b])]
+        assert abs(probs[b].sum() - 1.0) < 1e-4

@@ -321,7 +321,11 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
     //  3. those elements (value, index) are parked in LDS in (thread, element) order;
     //  4. one wave finishes on the candidates alone: bisection, the smallest kept value, the
     //     ties at that value and which of them (lowest indices first) stay.
-    auto ok = [&](float mass, int count) { return mass < tp && count < kk; };
+    // top_p >= 1 switches the mass test off altogether (05_mini_vllm/mini_vllm.py:619 applies the
+    // nucleus cut only `if top_p < 1.0`): with a peaked row the mass above the small entries
+    // rounds to 1.0f, and `mass < 1.0f` would drop them from a row that only has a top-k limit.
+    const bool use_p = tp < 1.0f;
+    auto ok = [&](float mass, int count) { return (!use_p || mass < tp) && count < kk; };
     float pmax = 0.f;
     for_each([&](float q, int) { pmax = fmaxf(pmax, q); });
     pmax = block_reduce(pmax, fmaxop, xch, slot);
