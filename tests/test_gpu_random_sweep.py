@@ -200,3 +200,57 @@ def test_sampler_random_rows(ops, device, seed):
             np.testing.assert_allclose(probs[b], want, rtol=2e-4, atol=1e-7)
         assert got_kept[int(ids[b])]
         assert abs(probs[b].sum() - 1.0) < 1e-4
+
+
+def _serve(mv, seed, graphs, lookahead):
+    """One randomly drawn serving run: engine limits, prompts (some sharing a prefix), generation
+    lengths and the step at which each request arrives all come from the seed."""
+    rng = np.random.default_rng(6000 + seed)
+    vocab = 12                                           # id 0 ends a sequence: sampled often, at unpredictable steps
+    block_size = int(rng.choice([4, 8, 16]))
+    slots = int(rng.choice([3, 8, 16]))
+    budget = int(rng.choice([24, 64, 256]))
+    prefix_caching = bool(rng.integers(0, 2))
+    n = int(rng.integers(6, 36))
+    shared = [int(t) for t in rng.integers(1, vocab, size=int(rng.integers(block_size, 3 * block_size + 1)))]
+    prompts = []
+    for _ in range(n):
+        own = [int(t) for t in rng.integers(1, vocab, size=int(rng.integers(1, 50)))]
+        prompts.append(shared + own if rng.random() < 0.4 else own)
+    max_new = [int(m) for m in rng.integers(1, 36, size=n)]
+    arrival = sorted(int(a) for a in np.where(rng.random(n) < 0.5, 0, rng.integers(0, 60, size=n)))
+    torch.manual_seed(7)
+    eng = mv.MiniVLLM(vocab_size=vocab, hidden_size=128, num_layers=2, num_heads=4, intermediate_size=256,
+                      num_kv_blocks=1024, block_size=block_size, max_num_seqs=slots, max_num_batched_tokens=budget,
+                      device='cuda', dtype=torch.float32, decode_graphs=graphs, decode_lookahead=lookahead,
+                      enable_prefix_caching=prefix_caching)
+    outs, ids, step, nxt = {}, [], 0, 0
+    while nxt < n or eng.scheduler.has_unfinished:
+        while nxt < n and arrival[nxt] <= step:
+            ids.append(eng.add_request(prompts[nxt], max_new_tokens=max_new[nxt], temperature=0.0))
+            nxt += 1
+        for rid, tok in eng.step():
+            outs.setdefault(rid, []).append(tok)
+        step += 1
+        assert step < 5000, 'the run does not end'
+    return eng, [outs.get(rid, []) for rid in ids], max_new
+
+
+@pytest.mark.parametrize('seed', range(10))
+def test_engine_random_serving_runs(device, seed):
+    """Requests that arrive while others run, more requests than sequence slots, token budgets that
+    chunk the prompts, shared prefixes with and without prefix caching: the engine that replays
+    captured decode steps, and the one that also issues them ahead, give every request exactly the
+    tokens of the engine that runs every step eagerly (greedy, fp32)."""
+    import mini_vllm as mv
+    eager, out_e, max_new = _serve(mv, seed, False, False)
+    plain, out_p, _ = _serve(mv, seed, True, False)
+    ahead, out_a, _ = _serve(mv, seed, True, True)
+    for toks, m in zip(out_e, max_new):
+        assert 1 <= len(toks) <= m and (len(toks) == m or toks[-1] == 0)
+    assert out_p == out_e
+    assert out_a == out_e
+    assert ahead._inflight is None
+    for eng in (eager, plain, ahead):
+        assert eng.allocator.num_free == 1024
+        assert not eng.scheduler.running and not eng.scheduler.waiting
