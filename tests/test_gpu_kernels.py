@@ -399,6 +399,31 @@ def test_decode_grouped_query_large_shape_properties(ops, device):
     torch.testing.assert_close(few.float(), out[:3].float(), **LOWP_TOL)
 
 
+def test_result_tensors_supplied_by_the_caller_are_checked(ops, device):
+    """`out=` must be the dense tensor the kernel writes; a view with other strides, another dtype or
+    another shape is refused instead of being written in the wrong places."""
+    rng = np.random.default_rng(3)
+    q, cache, bt, ctx = _random_batch(rng, 3, 8, 8, 64, 16, 40)
+    tq = torch.from_numpy(q).to(device)
+    tc = torch.from_numpy(cache).to(device)
+    tb = torch.from_numpy(bt).to(device)
+    cl = torch.tensor(ctx, dtype=torch.int32, device=device)
+    good = torch.empty_like(tq)
+    assert ops.paged_decode(tq, tc[0], tc[1], tb, cl, 40, out=good) is good
+    wide = torch.empty((3, 8, 128), device=device)
+    for bad in (wide[:, :, :64], torch.empty((3, 8, 64), dtype=torch.float16, device=device),
+                torch.empty((4, 8, 64), device=device), torch.empty((3, 8, 64))):
+        with pytest.raises(ValueError):
+            ops.paged_decode(tq, tc[0], tc[1], tb, cl, 40, out=bad)
+    logits = torch.randn(4, 100, device=device)
+    with pytest.raises(ValueError):
+        ops.sample_argmax(logits, out=torch.empty(3, dtype=torch.int32, device=device))
+    with pytest.raises(ValueError):
+        ops.sample_argmax(logits, out=torch.empty(4, dtype=torch.int64, device=device))
+    assert ops.sample_argmax(logits, out=torch.empty(6, dtype=torch.int32, device=device))[:4].tolist() == \
+        logits.argmax(dim=1).tolist()
+
+
 def test_decode_bad_arguments(ops, device):
     from mi355_paged._lib import Mi355Error
     q = torch.zeros((1, 8, 48), device=device)

@@ -98,6 +98,18 @@ def _stride(t: torch.Tensor, dim: int) -> int:
     return n
 
 
+def _checked_out(out: Optional[torch.Tensor], shape, dtype, dev) -> torch.Tensor:
+    """A caller-supplied result tensor must be exactly what the kernel writes: the kernels take a
+    bare pointer and assume a dense tensor of this shape, so anything else would be silently
+    written in the wrong places."""
+    if out is None:
+        return torch.empty(shape, dtype=dtype, device=dev)
+    if tuple(out.shape) != tuple(shape) or out.dtype != dtype or out.device != dev or not out.is_contiguous():
+        raise ValueError(f"out must be a contiguous {dtype} tensor of shape {tuple(shape)} on {dev}, got "
+                         f"{out.dtype} {tuple(out.shape)} strides {out.stride()} on {out.device}")
+    return out
+
+
 def _kv_geometry(cache: torch.Tensor, layout: str):
     if cache.dim() != 4:
         raise ValueError(f"KV cache must be 4-D ({layout}), got shape {tuple(cache.shape)}")
@@ -137,8 +149,7 @@ def paged_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
     context_lens = context_lens.contiguous()
     if block_tables.dim() != 2 or block_tables.shape[0] != B or context_lens.numel() != B:
         raise ValueError("block_tables must be [B, max_blocks] and context_lens [B]")
-    if out is None:
-        out = torch.empty((B, Hq, D), dtype=q.dtype, device=dev)
+    out = _checked_out(out, (B, Hq, D), q.dtype, dev)
     code = dtype_code(q)
     if scale is None:
         scale = 1.0 / math.sqrt(D)
@@ -238,6 +249,8 @@ def sample_argmax(logits: torch.Tensor, out: Optional[torch.Tensor] = None) -> t
     B, V = logits.shape
     if out is None:
         out = torch.empty((B,), dtype=torch.int32, device=dev)
+    elif out.dtype != torch.int32 or out.numel() < B or not out.is_contiguous() or out.device != dev:
+        raise ValueError("out must be a contiguous int32 vector of at least B entries on the logits' device")
     with _on(dev):
         rc = lib.mi355_sample_argmax(out.data_ptr(), logits.data_ptr(), B, V, _stride(logits, 0),
                                      dtype_code(logits), _stream(dev))
@@ -509,8 +522,7 @@ def paged_prefill(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
     if block_tables.dim() != 2 or block_tables.shape[0] != nseg or seg_q_start.numel() != nseg \
             or seg_pos0.numel() != nseg:
         raise ValueError("block_tables must be [nseg, max_blocks]; the segment vectors [nseg]")
-    if out is None:
-        out = torch.empty((T, Hq, D), dtype=q.dtype, device=dev)
+    out = _checked_out(out, (T, Hq, D), q.dtype, dev)
     if scale is None:
         scale = 1.0 / math.sqrt(D)
     with _on(dev):
