@@ -281,3 +281,24 @@ def test_module_bf16_on_device_config4_like(mla_mod, device):
     want, _, _ = mo.mla_forward(w, cfg, x.float().cpu().numpy(), pos.cpu().numpy(), past_c.float().cpu().numpy(),
                                 past_r.float().cpu().numpy(), dtype=np.float64)
     np.testing.assert_allclose(out.float().cpu().numpy(), want, atol=3e-2, rtol=5e-2)
+
+
+def test_mla_decode_rejects_contexts_beyond_the_cache(ops, device):
+    """The kernel reads max_context cache rows and rotary table rows per sequence: a bound larger
+    than either, or per-row vectors of the wrong length, are refused before the launch."""
+    q = torch.zeros((2, 4, 32 + 8), dtype=torch.bfloat16, device=device)
+    c_kv = torch.zeros((2, 10, 32), dtype=torch.bfloat16, device=device)
+    k_rope = torch.zeros((2, 10, 8), dtype=torch.bfloat16, device=device)
+    cos, sin = (torch.from_numpy(t).to(device) for t in mo.rope_tables(8, 10))
+    ctx = torch.tensor([10, 3], dtype=torch.int32, device=device)
+    ops.mla_decode(q, c_kv, k_rope, cos, sin, ctx, 10, 0.1)
+    with pytest.raises(ValueError):
+        ops.mla_decode(q, c_kv, k_rope, cos, sin, ctx, 11, 0.1)
+    with pytest.raises(ValueError):
+        ops.mla_decode(q, c_kv, k_rope, cos[:6], sin[:6], ctx, 10, 0.1)
+    with pytest.raises(ValueError):
+        ops.mla_decode(q, c_kv, k_rope[:, :9], cos, sin, ctx, 9, 0.1)
+    with pytest.raises(ValueError):
+        ops.mla_decode(q, c_kv, k_rope, cos, sin, ctx[:1], 10, 0.1)
+    with pytest.raises(ValueError):
+        ops.mla_decode(q, c_kv[:1], k_rope[:1], cos, sin, ctx, 10, 0.1)

@@ -343,6 +343,16 @@ def mla_decode(q: torch.Tensor, c_kv: torch.Tensor, k_rope: torch.Tensor, cos: t
         raise ValueError("cos / sin must be [table_len, rope_dim]")
     if context_lens.dtype != torch.int32 or (row_seq is not None and row_seq.dtype != torch.int32):
         raise TypeError("context_lens / row_seq must be int32")
+    if tuple(k_rope.shape[:2]) != tuple(c_kv.shape[:2]):
+        raise ValueError("c_kv and k_rope must hold the same [seqs, S] rows")
+    if context_lens.numel() != rows or (row_seq is not None and row_seq.numel() != rows):
+        raise ValueError("context_lens / row_seq must have one entry per query row")
+    if row_seq is None and rows > c_kv.shape[0]:
+        raise ValueError(f"{rows} query rows but {c_kv.shape[0]} cached sequences (pass row_seq to share them)")
+    # the kernel clamps each row's context to max_context and reads that many cache rows and table rows
+    if int(max_context) > c_kv.shape[1] or int(max_context) > cos.shape[0]:
+        raise ValueError(f"max_context {max_context} exceeds the cache rows ({c_kv.shape[1]}) or the "
+                         f"cos/sin table ({cos.shape[0]})")
     out = torch.empty((rows, H, R), dtype=torch.float32, device=dev)
     code = dtype_code(q)
     with _on(dev):
