@@ -21,7 +21,10 @@ modes = {
     'top_k=50,top_p=0.9': lambda x: ops.sample_topk_topp(x, temp, torch.full((B,), 0.9, device=dev),
                                                           torch.full((B,), 50, dtype=torch.int32, device=dev), seed=1),
 }
+only = os.environ.get('SAMPLER_MODES')
 for name, fn in modes.items():
+    if only and name not in only.split(';'):
+        continue
     for i in range(5):
         fn(logits[i % 4])
     n = 40

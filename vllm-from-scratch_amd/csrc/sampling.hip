@@ -195,6 +195,46 @@ struct FC {  // (probability mass, count) pair reduced together
   int c;
 };
 
+#ifndef SAMPLER_LEAN_MATH
+#define SAMPLER_LEAN_MATH 1
+#endif
+
+// a / b for a whole row that shares b, given y = 1.0f / b (one correctly rounded division per
+// row): the product a * y is within an ulp of the quotient, and one residual step
+// q + (a - b q) y, with the residual exact in an FMA, lands on the correctly rounded quotient --
+// the sequence the compiler emits for `/` without its scaling and fix-up steps, which only
+// matter for denormal or near-overflow operands.  Infinite a passes through (the residual
+// would be inf - inf).
+__device__ __forceinline__ float div_shared(float a, float b, float y) {
+#if SAMPLER_LEAN_MATH
+  const float q = a * y;
+  const float r = __builtin_fmaf(-b, q, a);
+  const float c = __builtin_fmaf(r, y, q);
+  return __builtin_fabsf(q) < __builtin_inff() ? c : q;
+#else
+  (void)y;
+  return a / b;
+#endif
+}
+
+// exp(d) for d <= 0 (softmax numerators).  d * log2(e) is formed as a rounded product plus its
+// rounding error (FMA) plus the low word of log2(e); the hardware exp2 takes the rounded part and
+// the rest is applied as a first-order factor: about an ulp, like the library routine, in six
+// instructions.  Results below the smallest normal float (d < -87.3, -inf included) are 0.
+__device__ __forceinline__ float exp_nonpos(float d) {
+#if SAMPLER_LEAN_MATH
+  constexpr float kL2eHi = 1.44269502162933349609375f, kL2eLo = 1.925963033500011e-8f, kLn2 = 0.693147182464599609375f;
+  const float t = d * kL2eHi;
+  float lo = __builtin_fmaf(d, kL2eHi, -t);
+  lo = __builtin_fmaf(d, kL2eLo, lo);
+  const float e = __builtin_amdgcn_exp2f(t);
+  const float r = __builtin_fmaf(e, lo * kLn2, e);
+  return d > -87.3f ? r : 0.f;
+#else
+  return expf(d);
+#endif
+}
+
 // VPT > 0: the row's probabilities live in registers (VPT per thread).
 // VPT == 0: they are recomputed from the logits on every pass (any vocab size).
 template <class Tag, int VPT, int NT>
@@ -231,29 +271,55 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
   constexpr int NR = VPT > 0 ? VPT : 1;
   float pr[NR];
   float mx = -__builtin_inff(), z = 0.f;
+  const float inv_t = 1.0f / temp;
+  // Rows that do not fit the registers are streamed from memory on every pass: fn(logit, index)
+  // for the thread's elements tid, tid + nt, ... in that order, kStreamU loads in flight per thread
+  // (the index is clamped instead of branching around the load, so that the loads of a group
+  // issue back to back; a load under a branch waits for its data before the next one starts).
+  constexpr int kStreamU = 8;
+  auto stream_row = [&](auto fn) {
+    for (int i0 = tid; i0 < vocab; i0 += nt * kStreamU) {
+      float x[kStreamU];
+#pragma unroll
+      for (int u = 0; u < kStreamU; ++u) x[u] = Tag::to_float(row[min(i0 + u * nt, vocab - 1)]);
+#pragma unroll
+      for (int u = 0; u < kStreamU; ++u)
+        if (i0 + u * nt < vocab) fn(x[u], i0 + u * nt);
+    }
+  };
   if constexpr (VPT > 0) {
+    // all of the thread's loads first (clamped index, no branch), then the arithmetic
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) pr[j] = Tag::to_float(row[min(j * nt + tid, vocab - 1)]);
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
-      const int i = j * nt + tid;
-      pr[j] = i < vocab ? Tag::to_float(row[i]) / temp : -__builtin_inff();
+      pr[j] = (j * nt + tid < vocab) ? div_shared(pr[j], temp, inv_t) : -__builtin_inff();
       mx = fmaxf(mx, pr[j]);
     }
     mx = block_reduce(mx, fmaxop, xch, slot);
+#if KO_STOP == 1
+    if (tid == 0) p.out[b] = (int)mx; return;
+#endif
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
-      pr[j] = expf(pr[j] - mx);          // absent elements: exp(-inf) = 0
+      pr[j] = exp_nonpos(pr[j] - mx);    // absent elements: exp(-inf) = 0
       z += pr[j];
     }
     z = block_reduce(z, addf, xch, slot);
+#if KO_STOP == 2
+    if (tid == 0) p.out[b] = (int)z; return;
+#endif
+    const float inv_z = 1.0f / z;
 #pragma unroll
-    for (int j = 0; j < VPT; ++j) pr[j] = (j * nt + tid < vocab) ? pr[j] / z : -1.0f;   // -1 marks "no element"
+    for (int j = 0; j < VPT; ++j) pr[j] = (j * nt + tid < vocab) ? div_shared(pr[j], z, inv_z) : -1.0f;   // -1 marks "no element"
   } else {
-    for (int i = tid; i < vocab; i += nt) mx = fmaxf(mx, Tag::to_float(row[i]) / temp);
+    stream_row([&](float x, int) { mx = fmaxf(mx, div_shared(x, temp, inv_t)); });
     mx = block_reduce(mx, fmaxop, xch, slot);
-    for (int i = tid; i < vocab; i += nt) z += expf(Tag::to_float(row[i]) / temp - mx);
+    stream_row([&](float x, int) { z += exp_nonpos(div_shared(x, temp, inv_t) - mx); });
     z = block_reduce(z, addf, xch, slot);
   }
-  auto prob_at = [&](int i) { return expf(Tag::to_float(row[i]) / temp - mx) / z; };
+  const float inv_z_row = 1.0f / z;
+  auto prob_of = [&](float x) { return div_shared(exp_nonpos(div_shared(x, temp, inv_t) - mx), z, inv_z_row); };
   // Visits every element this thread owns: fn(probability, index).
   auto for_each = [&](auto fn) {
     if constexpr (VPT > 0) {
@@ -261,7 +327,7 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
       for (int j = 0; j < VPT; ++j)
         if (pr[j] >= 0.f) fn(pr[j], j * nt + tid);
     } else {
-      for (int i = tid; i < vocab; i += nt) fn(prob_at(i), i);
+      stream_row([&](float x, int i) { fn(prob_of(x), i); });
     }
   };
   // (mass, count) of elements strictly above v, over the whole row.
@@ -305,9 +371,13 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
   int tie_end = vocab;
   const bool filter = tp < 1.0f || tk > 0;
   if (!filter) {
-    float s = 0.f;
-    for_each([&](float q, int) { s += q; });
-    kept_mass = block_reduce(s, addf, xch, slot);
+    // nothing is cut: the distribution is the softmax itself, as in the reference, which renormalises
+    // only after a cut (05_mini_vllm/mini_vllm.py:619-626).  The walked total can differ from 1 by
+    // rounding; a target beyond it falls to the last element (see the draw).
+    kept_mass = 1.0f;
+#if KO_STOP == 3
+    if (tid == 0) p.out[b] = (int)kept_mass; return;
+#endif
   } else {
     const int kk = tk > 0 ? tk : 0x7fffffff;
     // A value v survives (its first copy in descending order is kept) iff the mass strictly
@@ -563,13 +633,7 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
   // interval contains the target walks its own elements.
   const float target = philox_uniform(p.seed, p.offset + (uint64_t)b) * kept_mass;
   float mine = 0.f;
-  int last_kept = -1;
-  for_each([&](float q, int i) {
-    if (is_kept(q, i)) {
-      mine += q;
-      last_kept = max(last_kept, i);
-    }
-  });
+  for_each([&](float q, int i) { mine += is_kept(q, i) ? q : 0.f; });
   float incl = mine;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -580,27 +644,60 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
   if (tid == 0) s_pick = 0x7fffffff;
   __syncthreads();
   float base = 0.f;
-  for (int w = 0; w < wave; ++w) base += s_scan[w];
+#pragma unroll
+  for (int w = 0; w < kMaxWaves; ++w) base += w < wave ? s_scan[w] : 0.f;   // all reads issue together
   const float excl = base + incl - mine;
   if (mine > 0.f && excl <= target && target < excl + mine) atomicMin(&s_pick, tid);
   __syncthreads();
   const int picker = s_pick;
-  last_kept = block_reduce(last_kept, maxi, xch, slot);
   if (picker == 0x7fffffff) {
-    if (tid == 0) p.out[b] = max(last_kept, 0);  // rounding pushed the target past the total
+    // rounding pushed the target past the walked total (or between two threads' intervals): the
+    // last kept element takes it.  Rare, so its reduction stays off the common path.
+    int last_kept = -1;
+    for_each([&](float q, int i) { last_kept = is_kept(q, i) ? max(last_kept, i) : last_kept; });
+    last_kept = block_reduce(last_kept, maxi, xch, slot);
+    if (tid == 0) p.out[b] = max(last_kept, 0);
     return;
   }
-  if (tid == picker) {
-    float run = excl;
-    int choice = -1, fallback = -1;
-    for_each([&](float q, int i) {
-      if (is_kept(q, i)) {
-        fallback = i;
-        run += q;
-        if (choice < 0 && run > target) choice = i;
+  if constexpr (VPT > 0) {
+    // The picking thread's elements go through LDS to the lanes of wave 0, which finds the first one
+    // whose running sum passes the target with a prefix scan (one thread walking its 32 registers
+    // alone costs more than the rest of the draw).
+    __shared__ float s_walk[VPT];
+    __shared__ float s_walk_base;
+    if (tid == picker) {
+#pragma unroll
+      for (int j = 0; j < VPT; ++j) s_walk[j] = (pr[j] >= 0.f && is_kept(pr[j], j * nt + tid)) ? pr[j] : 0.f;
+      s_walk_base = excl;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const float q = lane < VPT ? s_walk[lane] : 0.f;
+      float run = q;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const float o = __shfl_up(run, off);
+        if (lane >= off) run += o;
       }
-    });
-    p.out[b] = choice >= 0 ? choice : fallback;
+      run += s_walk_base;
+      const unsigned long long hit = __ballot(q > 0.f && run > target);
+      const unsigned long long any = __ballot(q > 0.f);          // not empty: the picker's mass is > 0
+      const int j = hit ? __ffsll((long long)hit) - 1 : 63 - __clzll((long long)any);
+      if (lane == 0) p.out[b] = j * nt + picker;
+    }
+  } else {
+    if (tid == picker) {
+      float run = excl;
+      int choice = -1, fallback = -1;
+      for_each([&](float q, int i) {
+        if (is_kept(q, i)) {
+          fallback = i;
+          run += q;
+          if (choice < 0 && run > target) choice = i;
+        }
+      });
+      p.out[b] = choice >= 0 ? choice : fallback;
+    }
   }
 }
 
