@@ -11,7 +11,6 @@ namespace mi355 {
 namespace {
 
 constexpr int kMaxWaves = 16;
-constexpr int kCandCapMax = 1024;   // cut-search candidates one workgroup may park in LDS
 constexpr int kHistShift = 19;   // histogram key = probability bit pattern >> 19: exponent + 4 mantissa bits
 constexpr int kHistBins = 2048;  // keys of values in [0, 1] stay below 0x3F800000 >> 19 = 2032
 
@@ -245,22 +244,19 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
   // cut search state (see the filter section)
   __shared__ unsigned long long s_hist[kHistBins];
   __shared__ unsigned long long s_above;
-  constexpr int kCandCap = kCandCapMax;
-  __shared__ float s_cand[kCandCap];
-  __shared__ int s_cand_i[kCandCap];
-  __shared__ int s_cutbin;
-  __shared__ float s_res_f[2];
-  __shared__ int s_res_i[3];
+  __shared__ int s_cutbin, s_cutcount;
+  constexpr int kTieCap = 64;
+  __shared__ int s_tie_i[kTieCap];
+  __shared__ int s_tie_n;
   int slot = 0;
   const int tid = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
-  const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+  const int lane = tid & 63, wave = tid >> 6;
   const typename Tag::elem_t* row = static_cast<const typename Tag::elem_t*>(p.logits) + (int64_t)b * p.row_stride;
   const int vocab = p.vocab;
   const float temp = p.temperature[b];
   const float tp = p.top_p ? p.top_p[b] : 1.0f;
   const int tk = p.top_k ? p.top_k[b] : 0;
   auto fmaxop = [](float a, float c) { return fmaxf(a, c); };
-  auto fminop = [](float a, float c) { return fminf(a, c); };
   auto addf = [](float a, float c) { return a + c; };
   auto addi = [](int a, int c) { return a + c; };
   auto maxi = [](int a, int c) { return max(a, c); };
@@ -297,18 +293,12 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
       mx = fmaxf(mx, pr[j]);
     }
     mx = block_reduce(mx, fmaxop, xch, slot);
-#if KO_STOP == 1
-    if (tid == 0) p.out[b] = (int)mx; return;
-#endif
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
       pr[j] = exp_nonpos(pr[j] - mx);    // absent elements: exp(-inf) = 0
       z += pr[j];
     }
     z = block_reduce(z, addf, xch, slot);
-#if KO_STOP == 2
-    if (tid == 0) p.out[b] = (int)z; return;
-#endif
     const float inv_z = 1.0f / z;
 #pragma unroll
     for (int j = 0; j < VPT; ++j) pr[j] = (j * nt + tid < vocab) ? div_shared(pr[j], z, inv_z) : -1.0f;   // -1 marks "no element"
@@ -330,40 +320,6 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
       stream_row([&](float x, int i) { fn(prob_of(x), i); });
     }
   };
-  // (mass, count) of elements strictly above v, over the whole row.
-  auto above = [&](float v) {
-    FC a = {0.f, 0};
-    if constexpr (VPT > 0) {
-      // v >= 0 and absent elements are -1, so no presence test is needed here
-#pragma unroll
-      for (int j = 0; j < VPT; ++j) {
-        const bool up = pr[j] > v;
-        a.f += up ? pr[j] : 0.f;
-        a.c += up ? 1 : 0;
-      }
-    } else {
-      for_each([&](float q, int) {
-        if (q > v) {
-          a.f += q;
-          a.c += 1;
-        }
-      });
-    }
-    a.f = wave_reduce(a.f, addf);
-    a.c = wave_reduce(a.c, addi);
-    if (lane == 0) {
-      xch.f[slot][wave] = a.f;
-      xch.c[slot][wave] = a.c;
-    }
-    __syncthreads();
-    FC r = {xch.f[slot][0], xch.c[slot][0]};
-    for (int w = 1; w < nw; ++w) {
-      r.f += xch.f[slot][w];
-      r.c += xch.c[slot][w];
-    }
-    slot ^= 1;
-    return r;
-  };
 
   // Cut: elements with probability > vstar are kept, and of those equal to vstar
   // the ones with index < tie_end.  Default keeps everything.
@@ -375,239 +331,121 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
     // only after a cut (05_mini_vllm/mini_vllm.py:619-626).  The walked total can differ from 1 by
     // rounding; a target beyond it falls to the last element (see the draw).
     kept_mass = 1.0f;
-#if KO_STOP == 3
-    if (tid == 0) p.out[b] = (int)kept_mass; return;
-#endif
   } else {
     const int kk = tk > 0 ? tk : 0x7fffffff;
     // A value v survives (its first copy in descending order is kept) iff the mass strictly
     // above it is < top_p and fewer than k elements are above it: ok(mass, count).  That
-    // predicate is monotone in v, so the smallest surviving bit pattern can be bracketed and
-    // bisected.  Four stages, every sum in a fixed order (results repeat run to run):
-    //  1. histogram of the row over the top 12 bits of the probability's bit pattern (one
-    //     LDS atomic per element: count and fixed-point mass packed in 64 bits) -> the bin
-    //     that holds the cut, with the exact (mass, count) above that bin;
-    //  2. whole-row bisection passes only while more than kCandCap elements sit in the bracket;
-    //  3. those elements (value, index) are parked in LDS in (thread, element) order;
-    //  4. one wave finishes on the candidates alone: bisection, the smallest kept value, the
-    //     ties at that value and which of them (lowest indices first) stay.
+    // predicate is monotone in v, so the smallest surviving bit pattern is found by a radix
+    // search over the probability's bit pattern, most significant field first: 12 bits
+    // (exponent + 4 mantissa bits), then 11, then 8.  Each level is one pass of the whole
+    // workgroup over the row -- one LDS atomic per element that shares the prefix fixed so far,
+    // carrying its count and its mass in 2^-40 fixed point in one 64-bit add, so bin sums are
+    // exact and independent of the order of arrival -- and one scan of the bins by wave 0 for the
+    // lowest bin above which everything still passes ok().  After the last level the bin IS the
+    // smallest kept value, with the exact (mass, count) above it and the number of its copies.
     // top_p >= 1 switches the mass test off altogether (05_mini_vllm/mini_vllm.py:619 applies the
     // nucleus cut only `if top_p < 1.0`): with a peaked row the mass above the small entries
     // rounds to 1.0f, and `mass < 1.0f` would drop them from a row that only has a top-k limit.
     const bool use_p = tp < 1.0f;
     auto ok = [&](float mass, int count) { return (!use_p || mass < tp) && count < kk; };
-    float pmax = 0.f;
-    for_each([&](float q, int) { pmax = fmaxf(pmax, q); });
-    pmax = block_reduce(pmax, fmaxop, xch, slot);
-    const uint32_t pmax_bits = __builtin_bit_cast(uint32_t, pmax);
-
-    // ---- 1. histogram
-    for (int i = tid; i < kHistBins; i += nt) s_hist[i] = 0ull;
-    __syncthreads();
-    for_each([&](float q, int) {
-      const uint32_t key = __builtin_bit_cast(uint32_t, q) >> kHistShift;     // q in [0, 1] -> key < kHistBins
-      atomicAdd(&s_hist[key], (1ull << 41) + (unsigned long long)(q * 1099511627776.0f));   // count | q * 2^40
-    });
-    __syncthreads();
-    if (wave == 0) {
-      // lane l owns bins [l * kPer, (l + 1) * kPer); suffix sums over the lanes above it, then a walk
-      // down its own bins for the lowest one whose "everything above this bin" still passes ok()
-      constexpr int kPer = kHistBins / kWave;
-      unsigned long long own = 0ull;
+    constexpr unsigned long long kMassMask = (1ull << 41) - 1;
+    constexpr int kLevelShift[3] = {kHistShift, 8, 0};
+    constexpr int kLevelBits[3] = {11, 11, 8};        // level 0: bit 31 is the sign (0), keys < kHistBins
+    static_assert(kHistShift == 19 && kHistBins == 2048, "the three fields must tile the 32 bits");
+    unsigned long long acc = 0ull;     // packed (count | mass) of everything above the prefix's range
+    uint32_t prefix = 0;               // the bits fixed so far
+#pragma unroll
+    for (int L = 0; L < 3; ++L) {
+      const int shift = kLevelShift[L], nbins = 1 << kLevelBits[L], per = nbins / kWave;
+      for (int i = tid; i < nbins; i += nt) s_hist[i] = 0ull;
+      __syncthreads();
+      for_each([&](float q, int) {
+        const uint32_t bits = __builtin_bit_cast(uint32_t, q);
+        if (L == 0 || (bits >> (shift + kLevelBits[L])) == prefix)
+          atomicAdd(&s_hist[(bits >> shift) & (uint32_t)(nbins - 1)],
+                    (1ull << 41) + (unsigned long long)(q * 1099511627776.0f));   // count | q * 2^40
+      });
+      __syncthreads();
+      if (wave == 0) {
+        // lane l owns bins [l * per, (l + 1) * per); suffix sums over the lanes above it, then a walk
+        // down its own bins.  `run` = everything above the bin.  Passing bins form an upper range.
+        // The bins are re-read from LDS on each use: held in registers next to the thread's slice
+        // of the row they overflow the 128-register budget of a 1024-thread workgroup.
+        const int first = lane * per;
+        unsigned long long own = 0ull;
+#pragma unroll 8
+        for (int i = 0; i < per; ++i) own += s_hist[first + i];
+        unsigned long long incl = own;    // inclusive suffix scan: lanes >= l
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+          const unsigned long long o = __shfl_down(incl, off);
+          if (lane + off < kWave) incl += o;
+        }
+        const unsigned long long above_lane = acc + (incl - own);
+        unsigned long long run = above_lane;
+        int best = 0x7fffffff, top = -1;
 #pragma unroll 4
-      for (int i = 0; i < kPer; ++i) own += s_hist[lane * kPer + i];
-      unsigned long long incl = own;    // inclusive suffix scan: lanes >= l
-#pragma unroll
-      for (int off = 1; off < kWave; off <<= 1) {
-        const unsigned long long o = __shfl_down(incl, off);
-        if (lane + off < kWave) incl += o;
+        for (int i = per - 1; i >= 0; --i) {
+          const unsigned long long h = s_hist[first + i];
+          if (ok((float)(run & kMassMask) * 0x1p-40f, (int)(run >> 41))) best = first + i;
+          if (h != 0ull && top < 0) top = first + i;
+          run += h;
+        }
+        const int best_all = wave_reduce(best, mini);
+        const int top_all = wave_reduce(top, maxi);
+        // nothing passes (top_p <= 0): the largest value alone survives -> follow the top bin
+        const int sel = best_all != 0x7fffffff ? best_all : max(top_all, 0);
+        if (lane == sel / per) {
+          unsigned long long r = above_lane;
+          for (int bin = first + per - 1; bin > sel; --bin) r += s_hist[bin];
+          s_cutbin = sel;
+          s_above = r;
+          s_cutcount = (int)(s_hist[sel] >> 41);
+        }
       }
-      unsigned long long run = incl - own;   // sum of the bins above this lane's range
-      int best = 0x7fffffff;
-#pragma unroll 2
-      for (int i = kPer - 1; i >= 0; --i) {
-        const int b = lane * kPer + i;
-        const float mass = (float)(run & ((1ull << 41) - 1)) * 0x1p-40f;
-        if (ok(mass, (int)(run >> 41))) best = b;       // everything above bin b passes: b is a candidate cut bin
-        run += s_hist[b];
-      }
-      best = wave_reduce(best, mini);
-      if (lane == 0) s_cutbin = best;
+      __syncthreads();
+      prefix = (prefix << kLevelBits[L]) | (uint32_t)s_cutbin;
+      acc = s_above;
     }
-    __syncthreads();
-    int cutbin = s_cutbin;
-    if (cutbin == 0x7fffffff) cutbin = (int)(pmax_bits >> kHistShift);   // nothing passes (top_p <= 0): top bin
-    cutbin = min(cutbin, (int)(pmax_bits >> kHistShift));
-    // (mass, count) strictly above the cut bin, exact: integer sums of the histogram
-    if (wave == 0) {
-      constexpr int kPer = kHistBins / kWave;
-      unsigned long long part = 0ull;
-#pragma unroll 4
-      for (int i = 0; i < kPer; ++i) {
-        const int b = lane * kPer + i;
-        part += b > cutbin ? s_hist[b] : 0ull;
-      }
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
-      if (lane == 0) s_above = part;
+    vstar = __builtin_bit_cast(float, prefix);
+    const int ties = s_cutcount;
+    const FC a = {(float)(acc & kMassMask) * 0x1p-40f, (int)(acc >> 41)};   // strictly above vstar
+    // Of the `ties` copies of vstar, copy j (0-based, lowest index first -- the stable descending order)
+    // is kept iff mass_above + j * v < top_p and count_above + j < k.
+    int keep = ties;
+    if (use_p && vstar > 0.f) {
+      int jp = (int)fminf(ceilf((tp - a.f) / vstar), 2.0e9f);
+      while (jp > 0 && !(a.f + (float)(jp - 1) * vstar < tp)) --jp;
+      while (jp < ties && (a.f + (float)jp * vstar < tp)) ++jp;
+      keep = min(keep, jp);
     }
-    __syncthreads();
-    const unsigned long long packed_above = s_above;
-    uint32_t lo = (uint32_t)cutbin << kHistShift;
-    uint32_t hi = min((((uint32_t)cutbin + 1u) << kHistShift) - 1u, pmax_bits);
-    FC a_hi = {(float)(packed_above & ((1ull << 41) - 1)) * 0x1p-40f, (int)(packed_above >> 41)};   // strictly above hi
-    int n_ge_lo = a_hi.c + (int)(s_hist[cutbin] >> 41);                                            // elements >= lo
-
-    // ---- 2. whole-row passes while the bracket holds too many elements
-    while (lo < hi && n_ge_lo - a_hi.c > kCandCap) {
-      const uint32_t mid = lo + ((hi - lo) >> 1);
-      const FC a = above(__builtin_bit_cast(float, mid));
-      if (ok(a.f, a.c)) {
-        hi = mid;
-        a_hi = a;
-      } else {
-        lo = mid + 1;
-        n_ge_lo = a.c;
-      }
-    }
-
-    // ---- 3. candidates = elements with value in [lo, hi], in (thread, element) order
-    const float flo = __builtin_bit_cast(float, lo), fhi = __builtin_bit_cast(float, hi);
-    int mine_n = 0;
-    for_each([&](float q, int) { mine_n += (q >= flo && q <= fhi) ? 1 : 0; });
-    int incl_n = mine_n;
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-      const int o = __shfl_up(incl_n, off);
-      if (lane >= off) incl_n += o;
-    }
-    if (lane == kWave - 1) xch.c[slot][wave] = incl_n;
-    __syncthreads();
-    int base_n = 0, total_n = 0;
-    for (int w = 0; w < nw; ++w) {
-      const int c = xch.c[slot][w];
-      base_n += w < wave ? c : 0;
-      total_n += c;
-    }
-    slot ^= 1;
-    {
-      int at = base_n + incl_n - mine_n;
+    if (tk > 0) keep = min(keep, kk - a.c);
+    keep = max(keep, a.c == 0 ? 1 : 0);          // the top token always stays (05:624)
+    if (keep < ties && vstar > 0.f) {            // copies of an underflowed 0 carry no mass either way
+      // tie_end = 1 + the index of the keep-th copy in index order
+      if (tid == 0) s_tie_n = 0;
+      __syncthreads();
       for_each([&](float q, int i) {
-        if (q >= flo && q <= fhi) {
-          if (at < kCandCap) {
-            s_cand[at] = q;
-            s_cand_i[at] = i;
-          }
-          ++at;
+        if (q == vstar) {
+          const int at = atomicAdd(&s_tie_n, 1);
+          if (at < kTieCap) s_tie_i[at] = i;
         }
       });
-    }
-    __syncthreads();
-    const int ncand = min(total_n, kCandCap);   // total_n <= kCandCap unless lo == hi with many equal values
-
-    // ---- 4. one wave finishes on the candidates
-    if (wave == 0) {
-      // The candidates stay in LDS and are re-read on every use (a fixed number of independent reads
-      // per lane that pipeline; holding them in registers next to the thread's slice of the row
-      // overflows the 128-register budget of 1024 threads).  -1 stands for an empty slot.
-      constexpr int kPerLane = kCandCap / kWave;
-      auto cand = [&](int i) {
-        asm volatile("" ::: "memory");   // keep the read where it is used
-        const int at = lane + i * kWave;
-        return at < ncand ? s_cand[at] : -1.0f;
-      };
-      auto cand_above = [&](float v) {   // (mass, count) of all row elements strictly above v, v inside the bracket
-        float mf = 0.f;
-        int mc = 0;
-#pragma unroll
-        for (int i = 0; i < kPerLane; ++i) {
-          const float c = cand(i);
-          const bool up = c > v;
-          mf += up ? c : 0.f;
-          mc += up ? 1 : 0;
+      __syncthreads();
+      if (keep <= 0) {
+        tie_end = 0;
+      } else if (ties <= kTieCap) {
+        // few copies (the usual case: two or three values that happen to coincide): rank them in wave 0
+        if (wave == 0) {
+          const int mine_i = lane < ties ? s_tie_i[lane] : 0x7fffffff;
+          int rank = 0;
+          for (int m = 0; m < ties; ++m) rank += s_tie_i[m] < mine_i ? 1 : 0;
+          if (lane < ties && rank == keep - 1) s_cutbin = mine_i + 1;
         }
-        FC r;
-        r.f = wave_reduce(mf, addf) + a_hi.f;
-        r.c = wave_reduce(mc, addi) + a_hi.c;
-        return r;
-      };
-      while (lo < hi) {
-        const uint32_t mid = lo + ((hi - lo) >> 1);
-        const FC a = cand_above(__builtin_bit_cast(float, mid));
-        if (ok(a.f, a.c)) hi = mid; else lo = mid + 1;
-      }
-      const float u = __builtin_bit_cast(float, lo);
-      // smallest kept value = smallest candidate >= u (when the bracket collapsed onto one value with more
-      // copies than the candidate buffer holds, every copy equals that value)
-      float vmin = total_n > kCandCap ? fhi : __builtin_inff();
-      int ties_n = 0;
-#pragma unroll
-      for (int i = 0; i < kPerLane; ++i) {
-        const float c = cand(i);
-        if (c >= u) vmin = fminf(vmin, c);
-      }
-      vmin = wave_reduce(vmin, fminop);
-      if (vmin == __builtin_inff()) vmin = fhi;    // no candidate at or above u: cut at the bracket's top
-      const FC a = cand_above(vmin);
-#pragma unroll
-      for (int i = 0; i < kPerLane; ++i) ties_n += (cand(i) == vmin) ? 1 : 0;
-      ties_n = wave_reduce(ties_n, addi);
-      // Number of tied copies kept: copy j (0-based) needs mass_above + j*v < top_p and count_above + j < k.
-      const bool whole_row = total_n > kCandCap;      // more copies of one value than the buffer holds
-      int keep_n = ties_n, cut_index = vocab;
-      if (!whole_row) {
-        if (tp < 1.0f && vmin > 0.f) {
-          int jp = (int)fminf(ceilf((tp - a.f) / vmin), 2.0e9f);
-          while (jp > 0 && !(a.f + (float)(jp - 1) * vmin < tp)) --jp;
-          while (jp < ties_n && (a.f + (float)jp * vmin < tp)) ++jp;
-          keep_n = min(keep_n, jp);
-        }
-        if (tk > 0) keep_n = min(keep_n, kk - a.c);
-        keep_n = max(keep_n, a.c == 0 ? 1 : 0);
-        if (keep_n < ties_n) {
-          // keep the keep_n lowest-index copies: smallest X with #(ties at index < X) >= keep_n
-          int xl = 1, xh = vocab;
-          while (xl < xh) {
-            const int xm = xl + ((xh - xl) >> 1);
-            int c = 0;
-#pragma unroll
-            for (int i = 0; i < kPerLane; ++i) {
-              const bool tied = cand(i) == vmin;
-              c += (tied && s_cand_i[lane + i * kWave] < xm) ? 1 : 0;
-            }
-            c = wave_reduce(c, addi);
-            if (c >= keep_n) xh = xm; else xl = xm + 1;
-          }
-          cut_index = xl;
-        }
-      }
-      if (lane == 0) {
-        s_res_f[0] = vmin;
-        s_res_f[1] = a.f;
-        s_res_i[0] = a.c;
-        s_res_i[1] = whole_row ? -1 : keep_n;   // -1: ties are counted and cut over the whole row
-        s_res_i[2] = cut_index;
-      }
-    }
-    __syncthreads();
-    vstar = s_res_f[0];
-    const FC a = {s_res_f[1], s_res_i[0]};
-    int keep = s_res_i[1];
-    tie_end = s_res_i[2];
-    if (keep < 0) {
-      int t = 0;
-      for_each([&](float q, int) { t += (q == vstar); });
-      const int ties = block_reduce(t, addi, xch, slot);
-      keep = ties;
-      if (tp < 1.0f && vstar > 0.f) {
-        int jp = (int)fminf(ceilf((tp - a.f) / vstar), 2.0e9f);
-        while (jp > 0 && !(a.f + (float)(jp - 1) * vstar < tp)) --jp;
-        while (jp < ties && (a.f + (float)jp * vstar < tp)) ++jp;
-        keep = min(keep, jp);
-      }
-      if (tk > 0) keep = min(keep, kk - a.c);
-      keep = max(keep, a.c == 0 ? 1 : 0);
-      if (keep < ties) {
+        __syncthreads();
+        tie_end = s_cutbin;
+      } else {
+        // many equal values (constant stretches of the row): bisect on the index over the whole row
         int xl = 1, xh = vocab;
         while (xl < xh) {
           const int xm = xl + ((xh - xl) >> 1);
