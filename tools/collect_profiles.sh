@@ -60,6 +60,7 @@ step secondary benchmarks
   timeout -k 10 200 python3 tools/bench_engine.py 256 512 32
   timeout -k 10 200 python3 tools/bench_engine.py 128 256 64
   timeout -k 10 200 python3 tools/bench_engine.py 8 4096 8 1024
+  timeout -k 10 200 python3 tools/bench_engine_mixed.py 512 128 2048
   export MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0
   echo "one-rank RCCL communicator (BENCH_FORCE_DIST=1): gather every 4 steps, every step, native every step, none"
   BENCH_FORCE_DIST=1 timeout -k 10 200 python3 bench.py --no-cpu-baseline | cut -c1-200
