@@ -33,4 +33,5 @@ for rep in range(2):
     torch.cuda.synchronize()
     pr.disable()
     print(f'pass {rep}: {steps} steps, {(time.perf_counter() - t0) * 1e3:.1f} ms')
-pstats.Stats(pr).sort_stats('tottime').print_stats(30)
+pstats.Stats(pr).sort_stats('tottime').print_stats(22)
+pstats.Stats(pr).sort_stats('cumtime').print_stats(28)
