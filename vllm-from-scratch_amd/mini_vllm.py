@@ -316,20 +316,20 @@ class Scheduler:
         self.running = survivors
 
         still_waiting: List[Request] = []
-        for req in self.waiting:
-            admitted = False
-            if room():
-                if self.enable_prefix_caching and not req.block_table and req.num_computed_tokens == 0:
-                    self._adopt_cached_prefix(req)
-                first = req.num_computed_tokens           # 0 unless a cached prefix was adopted
-                left = req.prompt_len - first
-                want = min(left, budget) if chunked else left
-                if want > 0 and self._ensure_blocks(req, want):
-                    batch.append(self._emit(req, req.prompt_token_ids[first:first + want], first, True))
-                    budget -= want
-                    self.running.append(req)
-                    admitted = True
-            if not admitted:
+        for k, req in enumerate(self.waiting):
+            if not room():                             # room() never comes back within a step:
+                still_waiting.extend(self.waiting[k:])  # everybody behind stays queued, in order
+                break
+            if self.enable_prefix_caching and not req.block_table and req.num_computed_tokens == 0:
+                self._adopt_cached_prefix(req)
+            first = req.num_computed_tokens           # 0 unless a cached prefix was adopted
+            left = req.prompt_len - first
+            want = min(left, budget) if chunked else left
+            if want > 0 and self._ensure_blocks(req, want):
+                batch.append(self._emit(req, req.prompt_token_ids[first:first + want], first, True))
+                budget -= want
+                self.running.append(req)
+            else:
                 still_waiting.append(req)
         self.waiting = still_waiting
         return batch
@@ -1186,21 +1186,29 @@ class MiniVLLM:
         # the step's flattened (token, position, slot) vectors, by array arithmetic per request:
         # positions are consecutive from item.start, slot = block_table[pos // bs] * bs + pos % bs
         bs = self.scheduler.block_size
-        tok_parts, pos_parts, slot_parts = [], [], []
+        host_inputs = np.empty((3, sum(seq_lens)), dtype=np.int64)
+        tok_row, pos_row, slot_row = host_inputs
+        at = 0
         for item, n in zip(scheduled, seq_lens):
             req = item.request
-            if item.is_prefill and n > 1:
-                prompt = getattr(req, '_prompt_array', None)
-                if prompt is None:
-                    prompt = req._prompt_array = np.asarray(req.prompt_token_ids, dtype=np.int64)
-                tok_parts.append(prompt[item.start:item.start + n])
+            start = item.start
+            if n == 1:                                   # a decode token (or a one-token chunk): plain integers
+                tok_row[at] = item.tokens[0]
+                pos_row[at] = start
+                slot_row[at] = req.block_table[start // bs] * bs + start % bs
             else:
-                tok_parts.append(np.asarray(item.tokens, dtype=np.int64))
-            pos = np.arange(item.start, item.start + n, dtype=np.int64)
-            pos_parts.append(pos)
-            table = np.asarray(req.block_table, dtype=np.int64)
-            slot_parts.append(table[pos // bs] * bs + pos % bs)
-        host_inputs = np.stack([np.concatenate(tok_parts), np.concatenate(pos_parts), np.concatenate(slot_parts)])
+                if item.is_prefill:
+                    prompt = getattr(req, '_prompt_array', None)
+                    if prompt is None:
+                        prompt = req._prompt_array = np.asarray(req.prompt_token_ids, dtype=np.int64)
+                    tok_row[at:at + n] = prompt[start:start + n]
+                else:
+                    tok_row[at:at + n] = item.tokens
+                pos = np.arange(start, start + n, dtype=np.int64)
+                pos_row[at:at + n] = pos
+                table = np.asarray(req.block_table, dtype=np.int64)
+                slot_row[at:at + n] = table[pos // bs] * bs + pos % bs
+            at += n
 
         rows = None
         if not self.reference_compat:
