@@ -11,6 +11,11 @@ def _req(rid, table):
     return r
 
 
+def _rows(index):
+    """Token rows a plan entry stands for: a slice when they are consecutive, else a tensor."""
+    return list(range(index.start, index.stop)) if isinstance(index, slice) else index.tolist()
+
+
 def test_plan_all_prefill_from_position_zero_uses_one_causal_segment_per_request():
     plan = build_attn_plan([0, 1, 2, 0, 1], [3, 2], [True, True], [[4], [9]], 'cpu')
     assert plan.total_tokens == 5 and plan.causal_tokens == 5 and plan.paged_rows == 0
@@ -23,8 +28,8 @@ def test_plan_mixed_step_true_context():
     positions = [7, 4, 5, 6, 0, 1]
     plan = build_attn_plan(positions, [1, 3, 2], [False, True, True], [[3, 8], [5], [2]], 'cpu')
     assert plan.total_tokens == 6
-    assert plan.causal_index.tolist() == [4, 5] and plan.cu_seqlens.tolist() == [0, 2]
-    assert plan.paged_index.tolist() == [0, 1, 2, 3]
+    assert _rows(plan.causal_index) == [4, 5] and plan.cu_seqlens.tolist() == [0, 2]
+    assert _rows(plan.paged_index) == [0, 1, 2, 3]
     assert plan.paged_context.tolist() == [8, 5, 6, 7] and plan.max_context == 8
     assert plan.paged_tables.tolist() == [[3, 8], [5, 0], [5, 0], [5, 0]]      # padded with 0
 
@@ -34,8 +39,8 @@ def test_plan_reference_semantics_without_block_tables():
     decode row reads flat slot 0, like 05_mini_vllm/mini_vllm.py:437-481."""
     for kwargs in (dict(block_tables=None), dict(block_tables=[[3], [4]], reference_compat=True)):
         plan = build_attn_plan([5, 9, 10], [1, 2], [False, True], kwargs.pop('block_tables'), 'cpu', **kwargs)
-        assert plan.causal_index.tolist() == [1, 2] and plan.cu_seqlens.tolist() == [0, 2]
-        assert plan.paged_index.tolist() == [0]
+        assert _rows(plan.causal_index) == [1, 2] and plan.cu_seqlens.tolist() == [0, 2]
+        assert _rows(plan.paged_index) == [0]
         assert plan.paged_tables.tolist() == [[0]] and plan.paged_context.tolist() == [1]
 
 
@@ -256,13 +261,14 @@ def test_plan_later_chunks_become_append_segments_when_the_kernel_covers_the_mod
     positions = [7, 4, 5, 6, 0, 1, 9]
     args = (positions, [1, 3, 2, 1], [False, True, True, True], [[3, 8], [5, 6], [2], [4, 1, 7]], 'cpu')
     plan = build_attn_plan(*args, append_ok=True)
-    assert plan.causal_index.tolist() == [4, 5] and plan.cu_seqlens.tolist() == [0, 2]
-    assert plan.paged_index.tolist() == [0, 6] and plan.paged_context.tolist() == [8, 10]
+    assert _rows(plan.causal_index) == [4, 5] and plan.cu_seqlens.tolist() == [0, 2]
+    assert _rows(plan.paged_index) == [0, 6] and plan.paged_context.tolist() == [8, 10]
+    assert isinstance(plan.causal_index, slice) and not isinstance(plan.paged_index, slice)   # views where rows are consecutive
     assert plan.paged_tables.tolist() == [[3, 8, 0], [4, 1, 7]]
     assert plan.append_tokens == 3 and plan.append_meta.tolist() == [[1], [3], [4]]
     assert plan.append_tables.tolist() == [[5, 6]]
     assert plan.max_append_len == 3 and plan.max_append_context == 7
     # without the kernel the same tokens are paged-decode rows
     rows = build_attn_plan(*args)
-    assert rows.append_tokens == 0 and rows.paged_index.tolist() == [0, 1, 2, 3, 6]
+    assert rows.append_tokens == 0 and _rows(rows.paged_index) == [0, 1, 2, 3, 6]
     assert rows.paged_context.tolist() == [8, 5, 6, 7, 10]

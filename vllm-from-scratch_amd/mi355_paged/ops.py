@@ -203,9 +203,10 @@ def kv_write_slots(k_cache: torch.Tensor, v_cache: torch.Tensor, k: torch.Tensor
 
 
 def prefill_causal(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_seqlens: torch.Tensor,
-                   max_seqlen: int, scale: Optional[float] = None) -> torch.Tensor:
+                   max_seqlen: int, scale: Optional[float] = None,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Causal attention over packed sequences. q [T, Hq, D]; k, v [T, Hkv, D];
-    cu_seqlens [nseq + 1] int32 (device). Returns [T, Hq, D]."""
+    cu_seqlens [nseq + 1] int32 (device). Returns [T, Hq, D] (written into `out` when given)."""
     dev = require_device(q, k, v, cu_seqlens)
     lib = _lib.load()
 
@@ -226,7 +227,7 @@ def prefill_causal(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_seqlens
     if cu_seqlens.dtype != torch.int32:
         raise TypeError("cu_seqlens must be int32")
     cu_seqlens = cu_seqlens.contiguous()
-    out = torch.empty((T, Hq, D), dtype=q.dtype, device=dev)
+    out = _checked_out(out, (T, Hq, D), q.dtype, dev)
     if scale is None:
         scale = 1.0 / math.sqrt(D)
     with _on(dev):

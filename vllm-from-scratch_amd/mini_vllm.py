@@ -488,11 +488,12 @@ class AttnPlan:
     rows instead.
     """
     total_tokens: int
-    causal_index: Optional[torch.Tensor]      # int64 [Tc] token ids served by causal prefill (None = all)
+    causal_index: object                      # token rows served by causal prefill: None = all, a slice when they
+                                              # are consecutive (the usual case), else an int64 [Tc] device tensor
     cu_seqlens: Optional[torch.Tensor]        # int32 [nseg + 1]
     causal_tokens: int
     max_causal_len: int
-    paged_index: Optional[torch.Tensor]       # int64 [R] token ids served by paged decode (None = all)
+    paged_index: object                       # token rows served by paged decode, same three forms
     paged_tables: Optional[torch.Tensor]      # int32 [R, max_blocks]
     paged_context: Optional[torch.Tensor]     # int32 [R]
     paged_rows: int
@@ -565,6 +566,8 @@ def build_attn_plan(positions: Sequence[int], seq_lens: Sequence[int], is_prefil
     def idx(lst):
         if len(lst) == total:
             return None
+        if lst[-1] - lst[0] + 1 == len(lst):          # ascending and consecutive: a view, no gather / scatter
+            return slice(lst[0], lst[-1] + 1)
         return _upload(lst, torch.int64, device)
 
     plan = AttnPlan(total_tokens=total, causal_index=None, cu_seqlens=None, causal_tokens=len(causal_tok),
@@ -622,24 +625,31 @@ def paged_attention_step(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, k_ca
         k_cache.copy_(kc)
         v_cache.copy_(vc)
     out = None
+
+    def result_rows(sel):
+        """Where a kernel serving the token rows `sel` writes: the whole result, a view of it, or a
+        tensor of its own that is scattered afterwards."""
+        nonlocal out
+        if sel is None:
+            out = torch.empty(q.shape, dtype=q.dtype, device=dev)
+            return out
+        if out is None:
+            out = torch.empty(q.shape, dtype=q.dtype, device=dev)
+        return out[sel] if isinstance(sel, slice) else None
+
     if plan.causal_tokens:
         sel = plan.causal_index
+        dst = result_rows(sel)
         part = ops.prefill_causal(q if sel is None else q[sel], k if sel is None else k[sel],
-                                  v if sel is None else v[sel], plan.cu_seqlens, plan.max_causal_len, scale)
-        if sel is None:
-            out = part
-        else:
-            out = torch.empty(q.shape, dtype=q.dtype, device=dev)
+                                  v if sel is None else v[sel], plan.cu_seqlens, plan.max_causal_len, scale, out=dst)
+        if dst is None:
             out[sel] = part
     if plan.paged_rows:
         sel = plan.paged_index
+        dst = result_rows(sel)
         part = ops.paged_decode(q if sel is None else q[sel], kc, vc, plan.paged_tables,
-                                plan.paged_context, plan.max_context, layout='NSHD', scale=scale)
-        if sel is None:
-            out = part
-        else:
-            if out is None:
-                out = torch.empty(q.shape, dtype=q.dtype, device=dev)
+                                plan.paged_context, plan.max_context, layout='NSHD', scale=scale, out=dst)
+        if dst is None:
             out[sel] = part
     if plan.append_tokens:
         if out is None:
