@@ -492,6 +492,31 @@ def test_prefill_varlen_packed(ops, device, dtype):
                                **(F32_TOL if dtype == torch.float32 else LOWP_TOL))
 
 
+@pytest.mark.parametrize('shape', [
+    # Hq, Hkv, D, lens
+    (4, 4, 32, [1, 7, 8, 9, 33, 250]),          # the reference engine's default geometry; lengths around the group of 8
+    (8, 2, 64, [130, 5, 64]),                   # grouped heads: one workgroup per query head of the kv group
+    (6, 6, 128, [17, 300]),                     # six kv heads: two per workgroup, waves split the keys
+    (3, 1, 256, [40, 9]),
+])
+def test_prefill_fp32_row_groups_match_oracle_and_single_rows(ops, device, monkeypatch, shape):
+    """fp32 prompts run the VALU kernel with eight consecutive query rows per wave sharing each K/V
+    load; the result meets the oracle and the one-row-per-workgroup form of the same kernel."""
+    Hq, Hkv, D, lens = shape
+    rng = np.random.default_rng(sum(lens) + D)
+    T = sum(lens)
+    q, k, v = (torch.from_numpy(rng.standard_normal((T, h, D), dtype=np.float32)) for h in (Hq, Hkv, Hkv))
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    want = orc.varlen_causal_attention(q.numpy(), k.numpy(), v.numpy(), cu, dtype=np.float64)
+    args = (q.to(device), k.to(device), v.to(device), torch.from_numpy(cu).to(device), max(lens))
+    grouped = ops.prefill_causal(*args).cpu().numpy()
+    monkeypatch.setenv('MI355_PREFILL_ROW_GROUPS', '0')
+    single = ops.prefill_causal(*args).cpu().numpy()
+    np.testing.assert_allclose(grouped, want, **F32_TOL)
+    np.testing.assert_allclose(single, want, **F32_TOL)
+    np.testing.assert_allclose(grouped, single, atol=2e-6, rtol=1e-5)
+
+
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('D', [64, 128])
 def test_prefill_scores_that_keep_growing(ops, device, dtype, D):

@@ -1,0 +1,38 @@
+"""Causal prompt attention on the VALU kernel (fp32, or 16-bit at head dims the matrix-core kernel does not
+cover): row groups against one query row per workgroup (MI355_PREFILL_ROW_GROUPS=0).
+Usage: python tools/bench_prefill_fp32.py [nseq seqlen Hq Hkv D dtype]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'vllm-from-scratch_amd'))
+import torch
+from mi355_paged import ops
+
+args = sys.argv[1:]
+nseq, L, Hq, Hkv, D = [int(x) for x in args[:5]] if len(args) >= 5 else [16, 2048, 8, 8, 64]
+dtype = getattr(torch, args[5]) if len(args) > 5 else torch.float32
+dev = torch.device('cuda', 0)
+T = nseq * L
+q = torch.randn(T, Hq, D, device=dev, dtype=dtype)
+k = torch.randn(T, Hkv, D, device=dev, dtype=dtype)
+v = torch.randn(T, Hkv, D, device=dev, dtype=dtype)
+cu = torch.arange(0, T + 1, L, dtype=torch.int32, device=dev)
+flops = 4.0 * nseq * Hq * D * L * (L + 1) / 2
+os.environ['MI355_PREFILL_VALU'] = '1'
+outs = {}
+for name, env in (('row groups of 8', '1'), ('one row per workgroup', '0')):
+    os.environ['MI355_PREFILL_ROW_GROUPS'] = env
+    for _ in range(2):
+        outs[name] = ops.prefill_causal(q, k, v, cu, L)
+    n = 5
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        ops.prefill_causal(q, k, v, cu, L)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / n
+    print(f'{name}: nseq={nseq} len={L} Hq={Hq} Hkv={Hkv} D={D} {dtype}: {ms:.3f} ms  {flops / ms / 1e9:.1f} TFLOP/s', flush=True)
+vals = list(outs.values())
+print('max |difference| between the two:', (vals[0].float() - vals[1].float()).abs().max().item())

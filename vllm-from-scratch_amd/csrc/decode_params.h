@@ -18,6 +18,7 @@ struct DecodeParams {
   const int32_t* ctx;
   const int32_t* cu;  // non-null selects causal mode over packed sequences (VALU kernel only)
   int nseq;
+  int row_tiles;      // causal mode with row groups: tiles of consecutive query rows per sequence
   float* ws_acc;  // [B, Hq, nsplit, D]
   float* ws_ml;   // [B, Hq, nsplit, 2]  (max in log2 units, sum)
   int64_t q_stride_seq, s_blk, s_head, s_tok;

@@ -37,7 +37,11 @@ struct Geo {
   static_assert(LPT >= 1 && LPT <= kWave && (LPT & (LPT - 1)) == 0, "unsupported head_dim");
 };
 
-template <class Tag, int D, int G, int U, bool NT>
+// ROWS (causal mode only): the G slots of a wave are G consecutive query rows of one sequence and
+// one query head instead of G query heads of one row.  They share every K/V load -- row r reads
+// keys 0..r, so the group streams keys 0..last row once and masks, per slot, the few keys past
+// that slot's own position -- which divides the K/V traffic of prompt processing by G.
+template <class Tag, int D, int G, int U, bool NT, bool ROWS = false>
 __global__ void __launch_bounds__(kMaxThreads) paged_decode_kernel(const DecodeParams p) {
   constexpr int EPL = Geo<Tag, D>::EPL, LPT = Geo<Tag, D>::LPT, TPL = Geo<Tag, D>::TPL;
   constexpr int TS = TPL * U;  // tokens per pipeline step of one wave
@@ -58,7 +62,17 @@ __global__ void __launch_bounds__(kMaxThreads) paged_decode_kernel(const DecodeP
   // batch; it attends to tokens start..b of its own prompt, which sit in k/v rows
   // start..b (block_size 1, physical id = token row).  No block table is read.
   int ctx, lin_start = 0;
-  if (p.cu) {
+  int row0 = b, nrows = 1, ctx0 = 0;   // ROWS: first packed row of the group, rows in it, context of the first
+  if constexpr (ROWS) {
+    const int seq = b / p.row_tiles, first = (b % p.row_tiles) * G;
+    lin_start = p.cu[seq];
+    const int len = p.cu[seq + 1] - lin_start;
+    if (first >= len) return;          // the grid is sized for the longest sequence
+    nrows = min(G, len - first);
+    row0 = lin_start + first;
+    ctx0 = first + 1;
+    ctx = first + nrows;
+  } else if (p.cu) {
     int lo = 0, hi = p.nseq - 1;
     while (lo < hi) {  // largest s with cu[s] <= b
       const int mid = (lo + hi + 1) >> 1;
@@ -86,19 +100,21 @@ __global__ void __launch_bounds__(kMaxThreads) paged_decode_kernel(const DecodeP
 
   const int hslot = wave % p.hpw, sb = wave / p.hpw;
   const int kvh = hg * p.hpw + hslot;
-  const int len_w = p.tps / p.sub;
+  // ROWS: the group's own context is shared out between the sub-range waves (early groups are short)
+  const int len_w = ROWS ? (ctx + p.sub * TS - 1) / (p.sub * TS) * TS : p.tps / p.sub;
   const int tw0 = t0 + sb * len_w;
   const int tw1 = min(wg_end, tw0 + len_w);
   const int tl = lane / LPT, dg = lane % LPT;
 
   // Query fragments: this lane's EPL dims of each of the G query heads.
-  const int hq0 = kvh * p.gq + qc * G;
+  const int hq0 = ROWS ? kvh * p.gq + qc : kvh * p.gq + qc * G;
   typename Tag::QFrag qf[G];
 #pragma unroll
   for (int gi = 0; gi < G; ++gi) {
-    const int hq = (qc * G + gi < p.gq) ? hq0 + gi : hq0;
+    const int hq = ROWS ? hq0 : (qc * G + gi < p.gq) ? hq0 + gi : hq0;
+    const int qrow = ROWS ? row0 + min(gi, nrows - 1) : b;
     const char* src = static_cast<const char*>(p.q) +
-                      ((int64_t)b * p.q_stride_seq + (int64_t)hq * D + dg * EPL) * Tag::kBytes;
+                      ((int64_t)qrow * p.q_stride_seq + (int64_t)hq * D + dg * EPL) * Tag::kBytes;
     qf[gi] = Tag::make_q(load16<false>(src));
   }
 
@@ -133,11 +149,13 @@ __global__ void __launch_bounds__(kMaxThreads) paged_decode_kernel(const DecodeP
     float sc[G][U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const bool valid = tw0 + step * TS + u * TPL + tl < tw1;
+      const int tk = tw0 + step * TS + u * TPL + tl;
+      const bool valid = tk < tw1;
 #pragma unroll
       for (int gi = 0; gi < G; ++gi) {
         const float s = group_sum<LPT>(Tag::dot(qf[gi], kb[u]));
-        sc[gi][u] = valid ? s * p.scale_log2e : -__builtin_inff();
+        const bool seen = ROWS ? (valid && tk < ctx0 + gi) : valid;   // ROWS: slot gi sits at position ctx0 + gi - 1
+        sc[gi][u] = seen ? s * p.scale_log2e : -__builtin_inff();
       }
     }
 #pragma unroll
@@ -227,14 +245,15 @@ __global__ void __launch_bounds__(kMaxThreads) paged_decode_kernel(const DecodeP
   if (sb != 0 || lane >= LPT) return;
 #pragma unroll
   for (int gi = 0; gi < G; ++gi) {
-    if (qc * G + gi >= p.gq) continue;
-    const int hq = hq0 + gi;
-    if (p.nsplit == 1) {
+    if (ROWS ? gi >= nrows : qc * G + gi >= p.gq) continue;
+    const int hq = ROWS ? hq0 : hq0 + gi;
+    const int orow = ROWS ? row0 + gi : b;
+    if (ROWS || p.nsplit == 1) {
       const float inv = l[gi] > 0.f ? 1.f / l[gi] : 0.f;
       float o[EPL];
 #pragma unroll
       for (int e = 0; e < EPL; ++e) o[e] = acc[gi][e] * inv;
-      char* dst = static_cast<char*>(p.out) + (((int64_t)b * p.Hq + hq) * D + dg * EPL) * Tag::kBytes;
+      char* dst = static_cast<char*>(p.out) + (((int64_t)orow * p.Hq + hq) * D + dg * EPL) * Tag::kBytes;
       *reinterpret_cast<u32x4*>(dst) = Tag::pack(o);
     } else {
       const int64_t rec = ((int64_t)b * p.Hq + hq) * p.nsplit + sp;
@@ -441,6 +460,28 @@ int launch_decode(const DecodeParams& p, const DecodePlan& pl, hipStream_t strea
   if (int rc = check_launch("paged_decode_kernel")) return rc;
   if (p.nsplit > 1) return launch_merge<Tag, D>(p, stream);
   return 0;
+}
+
+// Prompt processing on the VALU kernel: row groups of kRowGroup consecutive query rows per wave.
+constexpr int kRowGroup = 8;
+template <class Tag, int D>
+int launch_causal_rows(const DecodeParams& p, size_t lds_bytes, hipStream_t stream) {
+  const int64_t grid = (int64_t)p.B * p.hgroups * p.qchunks;
+  hipLaunchKernelGGL((paged_decode_kernel<Tag, D, kRowGroup, steps_for_group(kRowGroup), false, true>),
+                     dim3((unsigned)grid), dim3(8 * kWave), lds_bytes, stream, p);
+  return check_launch("paged_decode_kernel (causal row groups)");
+}
+
+template <class Tag>
+int dispatch_causal_rows(int D, const DecodeParams& p, size_t lds_bytes, hipStream_t s) {
+  switch (D) {
+    case 16: return launch_causal_rows<Tag, 16>(p, lds_bytes, s);
+    case 32: return launch_causal_rows<Tag, 32>(p, lds_bytes, s);
+    case 64: return launch_causal_rows<Tag, 64>(p, lds_bytes, s);
+    case 128: return launch_causal_rows<Tag, 128>(p, lds_bytes, s);
+    case 256: return launch_causal_rows<Tag, 256>(p, lds_bytes, s);
+  }
+  return fail(MI355_EUNSUPPORTED, "head_dim %d", D);
 }
 
 // Matrix-core kernel for grouped-query shapes (+ the shared merge kernel when tokens are split).
@@ -724,7 +765,24 @@ extern "C" int mi355_prefill_causal(void* out, const void* q, const void* k, con
   p.nsplit = 1;
   p.lds_bt_bytes = (int)pl.lds_bt_bytes;
   p.scale_log2e = scale * 1.4426950408889634f;
+  p.row_tiles = 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // Row groups: one workgroup per (sequence, tile of kRowGroup query rows, kv-head group, query head of
+  // the kv group).  MI355_PREFILL_ROW_GROUPS=0 keeps one query row per workgroup (A/B measurements).
+  const size_t rows_lds = 16 + (pl.sub > 1 ? (size_t)pl.nw * kRowGroup * (D + 2) * sizeof(float) : 0);
+  const int64_t row_tiles = ((int64_t)max_seqlen + kRowGroup - 1) / kRowGroup;
+  const int64_t rows_grid = (int64_t)nseq * row_tiles * pl.hgroups * p.gq;
+  if (env_int("MI355_PREFILL_ROW_GROUPS", 1) && rows_lds <= 64 * 1024 && rows_grid < (1LL << 31)) {
+    p.row_tiles = (int)row_tiles;
+    p.B = (int)(nseq * row_tiles);
+    p.qchunks = p.gq;
+    p.lds_bt_bytes = 16;
+    switch (dtype) {
+      case MI355_F32: return dispatch_causal_rows<F32>(D, p, rows_lds, s);
+      case MI355_BF16: return dispatch_causal_rows<BF16>(D, p, rows_lds, s);
+      case MI355_F16: return dispatch_causal_rows<F16>(D, p, rows_lds, s);
+    }
+  }
   switch (dtype) {
     case MI355_F32: return dispatch_d<F32>(D, p, pl, s);
     case MI355_BF16: return dispatch_d<BF16>(D, p, pl, s);
