@@ -273,8 +273,9 @@ int mi355_decode_step_inputs(int64_t* token_ids, int64_t* positions, int64_t* sl
  *   block_tables[s][:]; query j attends to positions 0 .. seg_pos0[s] + j.
  *   q [T, Hq, D] (q_stride_tok elements between tokens), out [T, Hq, D] contiguous;
  *   max_q_len >= every seg_len, max_context >= every seg_pos0 + seg_len (host-side bounds).
- * bf16 / fp16 at head_dim 64 or 128 (matrix-core kernel); other shapes return
- * MI355_EUNSUPPORTED and the caller runs the tokens as rows of mi355_paged_decode.
+ * bf16 / fp16 at head_dim 64 or 128 run the matrix-core kernels; fp32 and head dims 16 / 32 / 256
+ * run the VALU kernel with eight consecutive query rows per wave.  Other head dims return
+ * MI355_EUNSUPPORTED.
  */
 int mi355_paged_prefill(void* out, const void* q, int64_t q_stride_tok,
                         const void* k_cache, const void* v_cache, const int32_t* block_tables,

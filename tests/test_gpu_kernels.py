@@ -282,12 +282,60 @@ def test_paged_prefill_clamps_bad_block_ids(ops, device):
 
 def test_paged_prefill_rejects_unsupported_shapes(ops, device):
     from mi355_paged._lib import Mi355Error
-    assert ops.paged_prefill_supported(torch.bfloat16, 64) and not ops.paged_prefill_supported(torch.float32, 64)
-    q = torch.zeros(4, 2, 32, dtype=torch.bfloat16, device=device)
-    cache = torch.zeros(2, 2, 16, 32, dtype=torch.bfloat16, device=device)
+    assert ops.paged_prefill_supported(torch.bfloat16, 64) and ops.paged_prefill_supported(torch.float32, 32)
+    assert not ops.paged_prefill_supported(torch.float32, 48)
+    q = torch.zeros(4, 2, 48, dtype=torch.bfloat16, device=device)
+    cache = torch.zeros(2, 2, 16, 48, dtype=torch.bfloat16, device=device)
     i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=device)
     with pytest.raises(Mi355Error, match='head_dim'):
         ops.paged_prefill(q, cache, cache, i32([[0, 1]]), i32([0]), i32([4]), i32([0]), 4, 4)
+
+
+@pytest.mark.parametrize('shape', [
+    # dtype, Hq, Hkv, D, BS, [(pos0, n_query_tokens), ...]
+    (torch.float32, 4, 4, 32, 16, [(0, 40), (130, 17), (5, 1), (64, 64)]),    # the reference engine's default geometry
+    (torch.float32, 8, 2, 64, 8, [(1000, 21), (3, 9)]),                       # grouped heads, long prefix
+    (torch.float32, 6, 6, 128, 3, [(10, 29)]),                                # block size not a power of two
+    (torch.bfloat16, 4, 4, 32, 16, [(33, 50), (0, 7)]),                       # 16-bit at a head_dim off the matrix-core path
+    (torch.float16, 2, 1, 256, 4, [(20, 30)]),
+])
+@pytest.mark.parametrize('layout', ['NHSD', 'NSHD'])
+def test_paged_prefill_segments_on_the_valu_kernel(ops, device, shape, layout):
+    """fp32 caches and head dims the matrix-core kernels do not take: chunks of new tokens over the
+    paged cache run the VALU kernel with eight consecutive query rows per wave; checked token by
+    token against the decode oracle, rows outside every segment untouched."""
+    dtype, Hq, Hkv, D, BS, segs = shape
+    rng = np.random.default_rng(Hq * 1000 + D + BS)
+    nseg = len(segs)
+    max_ctx = max(p0 + n for p0, n in segs)
+    per = (max_ctx + BS - 1) // BS
+    NB = nseg * per + 5
+    bt = rng.permutation(NB)[:nseg * per].reshape(nseg, per).astype(np.int32)
+    cache = torch.from_numpy(rng.standard_normal((2, NB, Hkv, BS, D), dtype=np.float32)).to(dtype)
+    T = sum(n for _, n in segs) + 3
+    q = torch.from_numpy(rng.standard_normal((T, Hq, D), dtype=np.float32)).to(dtype)
+    q0, starts = 2, []
+    for _, n in segs:
+        starts.append(q0)
+        q0 += n
+    tc = cache.to(device)
+    if layout == 'NSHD':
+        tc = tc.permute(0, 1, 3, 2, 4).contiguous()
+    out = torch.full((T, Hq, D), 7.0, dtype=dtype, device=device)
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=device)
+    ops.paged_prefill(q.to(device), tc[0], tc[1], torch.from_numpy(bt).to(device), i32(starts),
+                      i32([n for _, n in segs]), i32([p0 for p0, _ in segs]), max(n for _, n in segs), max_ctx,
+                      layout=layout, out=out)
+    got = out.float().cpu().numpy()
+    qn, cn = q.float().numpy(), cache.float().numpy()
+    owned = np.zeros(T, dtype=bool)
+    for s, (p0, n) in enumerate(segs):
+        for j in range(n):
+            row = starts[s] + j
+            owned[row] = True
+            want = orc.paged_decode(qn[row], cn[0], cn[1], bt[s].tolist(), p0 + j + 1, BS, dtype=np.float64)
+            np.testing.assert_allclose(got[row], want, **(F32_TOL if dtype == torch.float32 else LOWP_TOL))
+    assert (got[~owned] == 7.0).all()
 
 
 def test_decode_ignores_unused_and_clamps_bad_block_ids(ops, device):

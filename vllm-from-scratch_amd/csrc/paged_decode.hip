@@ -62,16 +62,27 @@ __global__ void __launch_bounds__(kMaxThreads) paged_decode_kernel(const DecodeP
   // batch; it attends to tokens start..b of its own prompt, which sit in k/v rows
   // start..b (block_size 1, physical id = token row).  No block table is read.
   int ctx, lin_start = 0;
-  int row0 = b, nrows = 1, ctx0 = 0;   // ROWS: first packed row of the group, rows in it, context of the first
+  int row0 = b, nrows = 1, ctx0 = 0;   // ROWS: first q / out row of the group, rows in it, context of the first
+  int bt_row = b;                      // row of the block table this workgroup reads
   if constexpr (ROWS) {
+    // packed prompts (p.cu): sequence `seq` owns rows cu[seq] .. cu[seq + 1] - 1 and starts at position 0;
+    // segments over the paged cache: rows seg_q0 .. + seg_len - 1, the first one at position seg_pos0
     const int seq = b / p.row_tiles, first = (b % p.row_tiles) * G;
-    lin_start = p.cu[seq];
-    const int len = p.cu[seq + 1] - lin_start;
-    if (first >= len) return;          // the grid is sized for the longest sequence
+    int len, pos0 = 0;
+    if (p.cu) {
+      lin_start = p.cu[seq];
+      len = p.cu[seq + 1] - lin_start;
+      row0 = lin_start + first;
+    } else {
+      len = p.seg_len[seq];
+      pos0 = max(p.seg_pos0[seq], 0);
+      row0 = p.seg_q0[seq] + first;
+      bt_row = seq;
+    }
+    if (first >= len) return;          // the grid is sized for the longest sequence / segment
     nrows = min(G, len - first);
-    row0 = lin_start + first;
-    ctx0 = first + 1;
-    ctx = first + nrows;
+    ctx0 = pos0 + first + 1;
+    ctx = p.cu ? first + nrows : min(pos0 + first + nrows, p.max_ctx);
   } else if (p.cu) {
     int lo = 0, hi = p.nseq - 1;
     while (lo < hi) {  // largest s with cu[s] <= b
@@ -93,7 +104,7 @@ __global__ void __launch_bounds__(kMaxThreads) paged_decode_kernel(const DecodeP
   const int lb0 = block_of(t0);
   const int nlb = (wg_end > t0 && !p.cu) ? block_of(wg_end - 1) - lb0 + 1 : 0;
   for (int i = tid; i < nlb; i += blockDim.x) {
-    int id = p.bt[(int64_t)b * p.max_blocks + lb0 + i];
+    int id = p.bt[(int64_t)bt_row * p.max_blocks + lb0 + i];
     s_bt[i] = min(max(id, 0), p.num_blocks - 1);
   }
   __syncthreads();
@@ -464,11 +475,17 @@ int launch_decode(const DecodeParams& p, const DecodePlan& pl, hipStream_t strea
 
 // Prompt processing on the VALU kernel: row groups of kRowGroup consecutive query rows per wave.
 constexpr int kRowGroup = 8;
+constexpr size_t kRowsMaxLds = 144 * 1024;   // of the 160 KB a CU has
 template <class Tag, int D>
 int launch_causal_rows(const DecodeParams& p, size_t lds_bytes, hipStream_t stream) {
   const int64_t grid = (int64_t)p.B * p.hgroups * p.qchunks;
-  hipLaunchKernelGGL((paged_decode_kernel<Tag, D, kRowGroup, steps_for_group(kRowGroup), false, true>),
-                     dim3((unsigned)grid), dim3(8 * kWave), lds_bytes, stream, p);
+  auto kernel = paged_decode_kernel<Tag, D, kRowGroup, steps_for_group(kRowGroup), false, true>;
+  if (lds_bytes > 64 * 1024) {   // beyond the default dynamic-LDS limit (head_dim 256 with waves splitting the keys)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds_bytes) != hipSuccess)
+      return fail(MI355_EUNSUPPORTED, "row-group kernel: %zu bytes of LDS refused", lds_bytes);
+  }
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(8 * kWave), lds_bytes, stream, p);
   return check_launch("paged_decode_kernel (causal row groups)");
 }
 
@@ -513,6 +530,80 @@ int dispatch_d(int D, const DecodeParams& p, const DecodePlan& pl, hipStream_t s
     case 256: return dispatch_g<Tag, 256>(p, pl, s);
   }
   return fail(MI355_EUNSUPPORTED, "head_dim %d", D);
+}
+
+// Chunks of new query tokens over the paged cache for the shapes the matrix-core kernels do not
+// take: the VALU kernel with kRowGroup consecutive query rows of a segment per wave.
+int paged_prefill_rows(void* out, const void* q, int64_t q_stride_tok, const void* k_cache, const void* v_cache,
+                       const int32_t* block_tables, const int32_t* seg_q0, const int32_t* seg_len,
+                       const int32_t* seg_pos0, int nseg, int max_q_len, int Hq, int Hkv, int D, int block_size,
+                       int max_blocks, int num_blocks, int max_context, int64_t s_blk, int64_t s_head,
+                       int64_t s_tok, float scale, int dtype, hipStream_t stream) {
+  if (dtype != MI355_F32 && dtype != MI355_BF16 && dtype != MI355_F16)
+    return fail(MI355_EINVAL, "paged_prefill: unknown dtype code %d", dtype);
+  if (D != 16 && D != 32 && D != 64 && D != 128 && D != 256)
+    return fail(MI355_EUNSUPPORTED, "paged_prefill: head_dim %d not in {16,32,64,128,256}", D);
+  const int epl = elems_per_lane(dtype);
+  if (s_blk <= 0 || s_head < 0 || s_tok <= 0 || s_blk >= (1LL << 31) || s_tok >= (1LL << 31) ||
+      (int64_t)Hkv * s_head + D >= (1LL << 31))
+    return fail(MI355_EINVAL, "paged_prefill: kv strides out of range");
+  if (s_blk % epl || s_head % epl || s_tok % epl || q_stride_tok % epl || q_stride_tok < (int64_t)Hq * D)
+    return fail(MI355_EINVAL, "paged_prefill: strides must keep head rows 16-byte aligned");
+  if (((uintptr_t)out | (uintptr_t)q | (uintptr_t)k_cache | (uintptr_t)v_cache) & 15)
+    return fail(MI355_EINVAL, "paged_prefill: tensors must be 16-byte aligned");
+  DecodeParams p;
+  p.out = out;
+  p.q = q;
+  p.kc = k_cache;
+  p.vc = v_cache;
+  p.bt = block_tables;
+  p.ctx = nullptr;
+  p.cu = nullptr;
+  p.nseq = nseg;
+  p.ws_acc = nullptr;
+  p.ws_ml = nullptr;
+  p.q_stride_seq = q_stride_tok;
+  p.s_blk = s_blk;
+  p.s_head = s_head;
+  p.s_tok = s_tok;
+  p.Hq = Hq;
+  p.Hkv = Hkv;
+  p.gq = Hq / Hkv;
+  p.block_size = block_size;
+  p.bs_shift = ilog2_exact(block_size);
+  p.max_blocks = max_blocks;
+  p.num_blocks = num_blocks;
+  p.max_ctx = max_context;
+  p.hpw = 8;
+  while (p.hpw > 1 && Hkv % p.hpw) p.hpw /= 2;
+  p.sub = 8 / p.hpw;
+  p.hgroups = Hkv / p.hpw;
+  p.qchunks = p.gq;
+  const int ts = (kWave / (D / epl)) * steps_for_group(kRowGroup);
+  const int quantum = p.sub * ts;
+  p.tps = (int)(ceil_div64(max_context, quantum) * quantum);
+  p.nsplit = 1;
+  if ((int64_t)p.tps / block_size + 2 > kMaxBtEntries)
+    return fail(MI355_EUNSUPPORTED, "paged_prefill: context %d with block_size %d exceeds the staged block table",
+                max_context, block_size);
+  p.lds_bt_bytes = (int)((size_t)((p.tps / block_size + 2) * 4 + 15) / 16 * 16);
+  const size_t lds = (size_t)p.lds_bt_bytes + (p.sub > 1 ? (size_t)8 * kRowGroup * (D + 2) * sizeof(float) : 0);
+  if (lds > kRowsMaxLds)
+    return fail(MI355_EUNSUPPORTED, "paged_prefill: context %d at head_dim %d needs %zu bytes of LDS", max_context, D, lds);
+  p.scale_log2e = scale * 1.4426950408889634f;
+  p.seg_q0 = seg_q0;
+  p.seg_len = seg_len;
+  p.seg_pos0 = seg_pos0;
+  p.n_qt = p.tq = p.hgp_shift = 0;
+  p.row_tiles = (max_q_len + kRowGroup - 1) / kRowGroup;
+  const int64_t groups = (int64_t)nseg * p.row_tiles;
+  if (groups * p.hgroups * p.qchunks >= (1LL << 31)) return fail(MI355_EINVAL, "paged_prefill: grid too large");
+  p.B = (int)groups;
+  switch (dtype) {
+    case MI355_F32: return dispatch_causal_rows<F32>(D, p, lds, stream);
+    case MI355_BF16: return dispatch_causal_rows<BF16>(D, p, lds, stream);
+    default: return dispatch_causal_rows<F16>(D, p, lds, stream);
+  }
 }
 
 }  // namespace
@@ -615,9 +706,12 @@ extern "C" int mi355_paged_prefill(void* out, const void* q, int64_t q_stride_to
       num_blocks <= 0 || max_context <= 0)
     return fail(MI355_EINVAL, "paged_prefill: bad shape");
   const int gq = Hq / Hkv;
-  if (!decode_gqa_supported(dtype, D, 4))
-    return fail(MI355_EUNSUPPORTED, "paged_prefill: 16-bit dtypes at head_dim 64 / 128 only (dtype %d, D %d)", dtype, D);
   if ((int64_t)max_context > (int64_t)max_blocks * block_size) max_context = max_blocks * block_size;
+  if (!decode_gqa_supported(dtype, D, 4))   // fp32, head dims off the matrix-core path: VALU kernel, row groups
+    return paged_prefill_rows(out, q, q_stride_tok, k_cache, v_cache, block_tables, seg_q_start, seg_len, seg_pos0,
+                              nseg, max_q_len, Hq, Hkv, D, block_size, max_blocks, num_blocks, max_context,
+                              kv_stride_block, kv_stride_head, kv_stride_tok, scale, dtype,
+                              static_cast<hipStream_t>(stream));
   if (kv_stride_block <= 0 || kv_stride_head < 0 || kv_stride_tok <= 0 || kv_stride_block >= (1LL << 31) ||
       kv_stride_tok >= (1LL << 31) || (int64_t)Hkv * kv_stride_head + D >= (1LL << 31))
     return fail(MI355_EINVAL, "paged_prefill: kv strides out of range");
@@ -772,7 +866,7 @@ extern "C" int mi355_prefill_causal(void* out, const void* q, const void* k, con
   const size_t rows_lds = 16 + (pl.sub > 1 ? (size_t)pl.nw * kRowGroup * (D + 2) * sizeof(float) : 0);
   const int64_t row_tiles = ((int64_t)max_seqlen + kRowGroup - 1) / kRowGroup;
   const int64_t rows_grid = (int64_t)nseq * row_tiles * pl.hgroups * p.gq;
-  if (env_int("MI355_PREFILL_ROW_GROUPS", 1) && rows_lds <= 64 * 1024 && rows_grid < (1LL << 31)) {
+  if (env_int("MI355_PREFILL_ROW_GROUPS", 1) && rows_lds <= kRowsMaxLds && rows_grid < (1LL << 31)) {
     p.row_tiles = (int)row_tiles;
     p.B = (int)(nseq * row_tiles);
     p.qchunks = p.gq;

@@ -500,10 +500,12 @@ def decode_step_inputs(packed: torch.Tensor, table_pool: torch.Tensor, block_siz
 
 
 def paged_prefill_supported(dtype: torch.dtype, head_dim: int) -> bool:
-    """Shapes mi355_paged_prefill serves (the matrix-core kernel); others go row by row through
-    paged_decode.  MI355_PAGED_PREFILL=0 forces the row path (A/B measurements)."""
+    """Shapes mi355_paged_prefill serves: 16-bit dtypes at head_dim 64 / 128 on the matrix-core
+    kernels, fp32 and the other head dims on the VALU kernel (eight query rows per wave).  Anything
+    else goes row by row through paged_decode.  MI355_PAGED_PREFILL=0 forces the row path (A/B
+    measurements)."""
     import os
-    return (dtype in (torch.bfloat16, torch.float16) and head_dim in (64, 128)
+    return (dtype in (torch.float32, torch.bfloat16, torch.float16) and head_dim in (16, 32, 64, 128, 256)
             and os.environ.get('MI355_PAGED_PREFILL', '1') != '0')
 
 
