@@ -54,7 +54,8 @@ step secondary benchmarks
   MI355_MLA_MANY_HEADS=0 MLA_TARGETS=0 timeout -k 10 120 python3 tools/bench_mla.py 128 128 4096 | tail -1 | sed 's/^/16 heads per workgroup: /'
   timeout -k 10 200 python3 tools/bench_small_batch.py
   for a in "16 2048 8 8 64" "2 16384 8 8 64" "16 2048 32 8 128" "4 8192 32 8 128" "64 512 32 8 128"; do BENCH_MFMA_ONLY=1 timeout -k 10 120 python3 tools/bench_prefill.py $a; done
-  timeout -k 10 120 python3 tools/bench_prefill.py 16 2048 8 8 64 | grep valu
+  timeout -k 10 120 python3 tools/bench_prefill_fp32.py 16 2048 8 8 64
+  timeout -k 10 120 python3 tools/bench_prefill_fp32.py 16 2048 4 4 32
   for a in "8 1024 3072 32 8 128" "8 1024 3072 8 8 64" "32 256 256 8 8 64" "64 64 1024 8 8 64"; do timeout -k 10 120 python3 tools/bench_paged_prefill.py $a; done
   timeout -k 10 200 python3 tools/bench_dtypes.py
   timeout -k 10 200 python3 tools/bench_engine.py 256 512 32
