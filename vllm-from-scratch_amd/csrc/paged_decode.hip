@@ -403,7 +403,7 @@ int make_plan(int B, int Hq, int Hkv, int D, int block_size, int max_context, in
   const int ts = pl.mfma ? kGqaTokens : (kWave / lpt) * steps_for_group(pl.G);  // tokens per wave per pipeline step
   const int ctx = max_context > 0 ? max_context : 1;
   // one 8-wave workgroup per CU, or two 4-wave ones, before tokens are split
-  const int target = env_int("MI355_PAGED_TARGET_WGS", pl.mfma ? 512 : 256);
+  const int target = env_int("MI355_PAGED_TARGET_WGS", 256);
   // Heads per workgroup.  Eight kv heads per workgroup fetch the eight head tiles of a block
   // (contiguous in the [block][head][row][d] layout) together.  When that leaves CUs idle,
   // fewer heads per workgroup with the freed waves taking token sub-ranges of the same head
