@@ -147,10 +147,13 @@ def paged_attention_decode(
     if isinstance(block_table, torch.Tensor) and block_table.is_cuda:
         # a table that already lives on the device is used where it is (no read-back)
         tables = block_table.to(device=dev, dtype=torch.int32).reshape(1, -1)
-        lens = torch.tensor([seq_len], dtype=torch.int32, device=dev)
+        lens = torch.tensor([seq_len], dtype=torch.int32).pin_memory().to(dev, non_blocking=True)
     else:
         # block table and context length travel in one host-to-device copy
-        packed = torch.tensor(_as_int_list(block_table) + [seq_len], dtype=torch.int32, device=dev)
+        # (through pinned memory and without blocking: a copy from pageable memory would wait for
+        # everything queued on the stream, i.e. for the previous decode step)
+        packed = torch.tensor(_as_int_list(block_table) + [seq_len], dtype=torch.int32)
+        packed = packed.pin_memory().to(dev, non_blocking=True)
         tables, lens = packed[:-1].unsqueeze(0), packed[-1:]
     out = ops.paged_decode(q, cache[0], cache[1], tables, lens, seq_len, layout='NHSD')
     return out[0].to(query.device)
