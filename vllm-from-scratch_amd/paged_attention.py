@@ -75,7 +75,7 @@ class KVCachePool:
         """Store one token's K and V rows ([kv_heads, head_dim] each)."""
         cache = self.kv_cache
         dev = _compute_device(cache, key, value)
-        slot = torch.tensor([block_id * self.block_size + slot_in_block], dtype=torch.int64, device=dev)
+        slot = _upload([block_id * self.block_size + slot_in_block], torch.int64, dev)
         k_rows = key.to(device=dev, dtype=cache.dtype).reshape(1, self.num_kv_heads, self.head_dim)
         v_rows = value.to(device=dev, dtype=cache.dtype).reshape(1, self.num_kv_heads, self.head_dim)
         if cache.is_cuda:
@@ -83,9 +83,16 @@ class KVCachePool:
         else:
             # host-resident pool: stage the touched block through the device and copy it back
             staged = cache[:, layer_idx, block_id].to(dev).unsqueeze(1).contiguous()  # [2,1,H,BS,D]
-            local = torch.tensor([slot_in_block], dtype=torch.int64, device=dev)
+            local = _upload([slot_in_block], torch.int64, dev)
             ops.kv_write_slots(staged[0], staged[1], k_rows, v_rows, local, 'NHSD')
             cache[:, layer_idx, block_id].copy_(staged[:, 0])
+
+
+def _upload(values, dtype: torch.dtype, dev: torch.device) -> torch.Tensor:
+    """Small host integers -> device tensor through pinned memory, without blocking (a copy from
+    pageable memory waits for everything already queued on the stream)."""
+    t = torch.tensor(values, dtype=dtype)
+    return t.pin_memory().to(dev, non_blocking=True) if dev.type == 'cuda' else t.to(dev)
 
 
 def compute_slot_mapping(block_table: List[int], seq_len: int, block_size: int) -> List[int]:
@@ -147,13 +154,12 @@ def paged_attention_decode(
     if isinstance(block_table, torch.Tensor) and block_table.is_cuda:
         # a table that already lives on the device is used where it is (no read-back)
         tables = block_table.to(device=dev, dtype=torch.int32).reshape(1, -1)
-        lens = torch.tensor([seq_len], dtype=torch.int32).pin_memory().to(dev, non_blocking=True)
+        lens = _upload([seq_len], torch.int32, dev)
     else:
         # block table and context length travel in one host-to-device copy
         # (through pinned memory and without blocking: a copy from pageable memory would wait for
         # everything queued on the stream, i.e. for the previous decode step)
-        packed = torch.tensor(_as_int_list(block_table) + [seq_len], dtype=torch.int32)
-        packed = packed.pin_memory().to(dev, non_blocking=True)
+        packed = _upload(_as_int_list(block_table) + [seq_len], torch.int32, dev)
         tables, lens = packed[:-1].unsqueeze(0), packed[-1:]
     out = ops.paged_decode(q, cache[0], cache[1], tables, lens, seq_len, layout='NHSD')
     return out[0].to(query.device)
@@ -177,14 +183,14 @@ def paged_attention_prefill(
     q = query.to(dev)
     k = key.to(device=dev, dtype=kv_cache.dtype)
     v = value.to(device=dev, dtype=kv_cache.dtype)
-    slot_t = torch.tensor(slots, dtype=torch.int64, device=dev)
+    slot_t = _upload(slots, torch.int64, dev)
     if kv_cache.is_cuda:
         ops.kv_write_slots(kv_cache[0], kv_cache[1], k, v, slot_t, 'NHSD')
     else:
         staged = kv_cache.to(dev)
         ops.kv_write_slots(staged[0], staged[1], k, v, slot_t, 'NHSD')
         kv_cache.copy_(staged)
-    cu = torch.tensor([0, seq_len], dtype=torch.int32, device=dev)
+    cu = _upload([0, seq_len], torch.int32, dev)
     out = ops.prefill_causal(q, key.to(device=dev, dtype=q.dtype), value.to(device=dev, dtype=q.dtype),
                              cu, seq_len)
     return out.to(query.device)
