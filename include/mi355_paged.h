@@ -146,7 +146,11 @@ int mi355_sample_argmax(int32_t* out_ids, const void* logits, int32_t B, int32_t
  *   seed/offset select the counter-based random stream: row b draws from
  *   philox(seed, offset + b).
  *   out_probs: optional [B, vocab] float; when non-NULL receives the
- *   renormalised post-filter distribution (for tests / inspection).
+ *   renormalised post-filter distribution (for tests / inspection).  A row
+ *   without a cut (top_p >= 1, no top-k) keeps the softmax as it is, like the
+ *   reference, which renormalises only after a cut (:619-626).
+ *   Probabilities below the smallest normal float are taken as 0; a NaN logit gets
+ *   probability 0 (it is never drawn), unlike mi355_sample_argmax above.
  */
 int mi355_sample_topk_topp(int32_t* out_ids, const void* logits, const float* temperature,
                            const float* top_p, const int32_t* top_k, uint64_t seed,
