@@ -740,6 +740,32 @@ def test_sampling_filters_match_oracle(ops, device, vocab):
         assert abs(probs[b].sum() - 1.0) < 1e-4
 
 
+def test_sampling_gives_nan_and_minus_inf_logits_probability_zero(ops, device):
+    """Masked (-inf) and NaN logits carry no probability: the rest of the row is the softmax of the
+    finite entries, and neither kind is ever drawn."""
+    rng = np.random.default_rng(5)
+    vocab = 1000
+    logits = rng.standard_normal((4, vocab)).astype(np.float32)
+    logits[:, 10] = -np.inf
+    logits[1, 20] = np.nan
+    logits[2, 0:500] = -np.inf
+    logits[3, 7] = np.nan
+    temp = torch.ones(4, device=device)
+    ids, probs = ops.sample_topk_topp(torch.from_numpy(logits).to(device), temp, None, None, seed=3, return_probs=True)
+    probs = probs.cpu().numpy()
+    for b in range(4):
+        finite = np.isfinite(logits[b])
+        want = np.zeros(vocab)
+        e = np.exp(logits[b][finite].astype(np.float64) - logits[b][finite].max())
+        want[finite] = e / e.sum()
+        np.testing.assert_allclose(probs[b], want, rtol=2e-4, atol=1e-9)
+        assert finite[int(ids[b])]
+    draws = torch.stack([ops.sample_topk_topp(torch.from_numpy(logits).to(device), temp, None, None, seed=s)
+                         for s in range(50)]).cpu().numpy()
+    for b in range(4):
+        assert np.isfinite(logits[b][draws[:, b]]).all()
+
+
 def test_sampling_top_k_without_top_p_on_a_peaked_row(ops, device):
     """top_p = 1 means "no nucleus cut" (05_mini_vllm/mini_vllm.py:619), also when a top-k limit is set:
     on a peaked row the mass above the small entries rounds to 1.0f, and a `mass < top_p` test
