@@ -254,3 +254,84 @@ def test_engine_random_serving_runs(device, seed):
     for eng in (eager, plain, ahead):
         assert eng.allocator.num_free == 1024
         assert not eng.scheduler.running and not eng.scheduler.waiting
+
+
+LAYER_TOL = {torch.float32: dict(atol=1e-5, rtol=1e-5), torch.bfloat16: dict(atol=2e-2, rtol=2e-2),
+             torch.float16: dict(atol=3e-3, rtol=3e-3)}
+
+
+def _rotate_half(x):
+    lo, hi = x.chunk(2, dim=-1)
+    return torch.cat((-hi, lo), dim=-1)
+
+
+@pytest.mark.parametrize('seed', range(18))
+def test_layer_steps_random_shapes(ops, device, seed):
+    """RMSNorm (+ carried residual), the SwiGLU gate and RoPE + KV write on randomly drawn widths, row
+    counts, head geometries, block sizes and cache layouts, against the torch expressions."""
+    g = torch.Generator().manual_seed(7000 + seed)
+    rnd = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    dtype = DTYPES[seed % 3]
+    per16 = 16 // torch.empty((), dtype=dtype).element_size()
+    tol = LAYER_TOL[dtype]
+
+    # rmsnorm over [T, hidden] rows that are a column slice of a wider activation
+    T, hidden = rnd(1, 300), per16 * rnd(1, 4096 // per16 // (2 if dtype == torch.float32 else 1))
+    wide = (torch.randn(T, hidden + per16 * rnd(0, 3), generator=g) * 3).to(dtype).to(device)
+    x = wide[:, :hidden]
+    delta = torch.randn(T, hidden, generator=g).to(dtype).to(device)
+    w = (1 + 0.1 * torch.randn(hidden, generator=g)).to(dtype).to(device)
+    eps = [1e-6, 1e-5][seed % 2]
+
+    def norm(t):
+        t = t.float()
+        return w.float() * (t / (t * t).mean(-1, keepdim=True).add(eps).sqrt())
+
+    torch.testing.assert_close(ops.rmsnorm(x, w, eps).float(), norm(x), **tol)
+    total, normed = ops.rmsnorm(x, w, eps, delta=delta)
+    assert torch.equal(total, (x.float() + delta.float()).to(dtype))
+    torch.testing.assert_close(normed.float(), norm(total), **tol)
+
+    # silu(gate) * up on the two halves of one projection output
+    width = per16 * rnd(1, 400)
+    both = (torch.randn(T, 2 * width, generator=g) * 4).to(dtype).to(device)
+    torch.testing.assert_close(ops.silu_mul(both[:, :width], both[:, width:]).float(),
+                               torch.nn.functional.silu(both[:, :width].float()) * both[:, width:].float(), **tol)
+
+    # RoPE in place on q and k (views of one qkv projection) + write of k, v into the paged caches
+    Hkv = [1, 2, 4, 8][rnd(0, 3)]
+    Hq = Hkv * [1, 2, 4][rnd(0, 2)]
+    D = [16, 32, 64, 128][rnd(0, 3)]
+    BS = [1, 3, 4, 16, 32][rnd(0, 4)]
+    layout = ['NSHD', 'NHSD'][seed % 2]
+    qkv = torch.randn(T, (Hq + 2 * Hkv) * D, generator=g).to(dtype).to(device)
+    q, k, v = (t.view(T, -1, D) for t in qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1))
+    inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2).float() / D))
+    ang = torch.outer(torch.arange(700).float(), inv)
+    cos, sin = (torch.cat([f(ang), f(ang)], -1).to(dtype).to(device) for f in (torch.cos, torch.sin))
+    pos = torch.randint(0, 700, (T,), generator=g).to(device)
+    NB = (T + BS - 1) // BS + 2
+    slots = torch.randperm(NB * BS, generator=g)[:T].to(device)
+    slots[rnd(0, T - 1)] = -1                                  # a row that is rotated but not stored
+    shape = (NB, BS, Hkv, D) if layout == 'NSHD' else (NB, Hkv, BS, D)
+    kc = torch.zeros(shape, dtype=dtype, device=device)
+    vc = torch.zeros_like(kc)
+    c, s = cos[pos].float().unsqueeze(1), sin[pos].float().unsqueeze(1)
+    want_q, want_k = q.float() * c + _rotate_half(q.float()) * s, k.float() * c + _rotate_half(k.float()) * s
+    v0 = v.clone()
+    ops.rope_kv_write(q, k, v, cos, sin, pos, slots, kc, vc, layout=layout)
+    torch.testing.assert_close(q.float(), want_q, **tol)
+    torch.testing.assert_close(k.float(), want_k, **tol)
+    assert torch.equal(v, v0)
+    flat = (lambda t: t.reshape(NB * BS, Hkv, D)) if layout == 'NSHD' else \
+        (lambda t: t.permute(0, 2, 1, 3).reshape(NB * BS, Hkv, D))
+    keep = slots >= 0
+    assert torch.equal(flat(kc)[slots[keep]], k[keep]) and torch.equal(flat(vc)[slots[keep]], v[keep])
+    untouched = torch.ones(NB * BS, dtype=torch.bool, device=device)
+    untouched[slots[keep]] = False
+    assert not flat(kc)[untouched].any() and not flat(vc)[untouched].any()
+
+    # the plain slot write gives the same cache contents
+    kc2, vc2 = torch.zeros_like(kc), torch.zeros_like(vc)
+    ops.kv_write_slots(kc2, vc2, k[keep], v[keep], slots[keep], layout=layout)
+    assert torch.equal(kc2, kc) and torch.equal(vc2, vc)
