@@ -548,8 +548,9 @@ def test_prefill_varlen_packed(ops, device, dtype):
     (3, 1, 256, [40, 9]),
 ])
 def test_prefill_fp32_row_groups_match_oracle_and_single_rows(ops, device, monkeypatch, shape):
-    """fp32 prompts run the VALU kernel with eight consecutive query rows per wave sharing each K/V
-    load; the result meets the oracle and the one-row-per-workgroup form of the same kernel."""
+    """fp32 prompts: one query row per lane at head_dim 32 / 64, elsewhere the decode-shaped kernel with
+    eight consecutive query rows per wave sharing each K/V load; both meet the oracle and the
+    one-row-per-workgroup form of the decode-shaped kernel."""
     Hq, Hkv, D, lens = shape
     rng = np.random.default_rng(sum(lens) + D)
     T = sum(lens)
@@ -557,12 +558,15 @@ def test_prefill_fp32_row_groups_match_oracle_and_single_rows(ops, device, monke
     cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
     want = orc.varlen_causal_attention(q.numpy(), k.numpy(), v.numpy(), cu, dtype=np.float64)
     args = (q.to(device), k.to(device), v.to(device), torch.from_numpy(cu).to(device), max(lens))
+    default = ops.prefill_causal(*args).cpu().numpy()          # head_dim 32 / 64: one query row per lane
+    monkeypatch.setenv('MI355_PREFILL_F32_TILED', '0')
     grouped = ops.prefill_causal(*args).cpu().numpy()
     monkeypatch.setenv('MI355_PREFILL_ROW_GROUPS', '0')
     single = ops.prefill_causal(*args).cpu().numpy()
-    np.testing.assert_allclose(grouped, want, **F32_TOL)
-    np.testing.assert_allclose(single, want, **F32_TOL)
+    for got in (default, grouped, single):
+        np.testing.assert_allclose(got, want, **F32_TOL)
     np.testing.assert_allclose(grouped, single, atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(default, single, atol=2e-6, rtol=1e-5)
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
