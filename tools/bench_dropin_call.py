@@ -1,3 +1,5 @@
+"""Per-call time of the drop-in paged_attention.paged_attention_decode for one sequence: device-resident
+tensors, a block table that already lives on the device, and host-resident tensors staged per call."""
 import sys, time, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'vllm-from-scratch_amd'))
 import torch

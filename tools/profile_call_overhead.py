@@ -1,3 +1,4 @@
+"""cProfile of repeated ops.paged_decode calls on a small problem: where the host time of one call goes."""
 import cProfile, pstats, sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'vllm-from-scratch_amd'))
 import torch

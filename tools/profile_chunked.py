@@ -1,5 +1,6 @@
+"""cProfile of MiniVLLM steps with chunked prompts (host time per function)."""
 import cProfile, pstats, sys, os, time
-sys.path.insert(0, '/root/repo/vllm-from-scratch_amd')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'vllm-from-scratch_amd'))
 import torch
 import mini_vllm as mv
 torch.manual_seed(0)
