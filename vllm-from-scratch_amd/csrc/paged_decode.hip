@@ -67,7 +67,9 @@ __global__ void __launch_bounds__(kMaxThreads) paged_decode_kernel(const DecodeP
   if constexpr (ROWS) {
     // packed prompts (p.cu): sequence `seq` owns rows cu[seq] .. cu[seq + 1] - 1 and starts at position 0;
     // segments over the paged cache: rows seg_q0 .. + seg_len - 1, the first one at position seg_pos0
-    const int seq = b / p.row_tiles, first = (b % p.row_tiles) * G;
+    // index order = dispatch order: the last (longest) row tiles of every sequence first, so that the
+    // short ones fill the tail instead of one long wave finishing alone
+    const int seq = b % p.nseq, first = (p.row_tiles - 1 - b / p.nseq) * G;
     int len, pos0 = 0;
     if (p.cu) {
       lin_start = p.cu[seq];
