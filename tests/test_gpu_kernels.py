@@ -548,7 +548,7 @@ def test_prefill_varlen_packed(ops, device, dtype):
     (3, 1, 256, [40, 9]),
 ])
 def test_prefill_fp32_row_groups_match_oracle_and_single_rows(ops, device, monkeypatch, shape):
-    """fp32 prompts: one query row per lane at head_dim 32 / 64, elsewhere the decode-shaped kernel with
+    """fp32 prompts: one query row per lane at head_dim 32 / 64 / 128, elsewhere the decode-shaped kernel with
     eight consecutive query rows per wave sharing each K/V load; both meet the oracle and the
     one-row-per-workgroup form of the decode-shaped kernel."""
     Hq, Hkv, D, lens = shape
@@ -558,7 +558,7 @@ def test_prefill_fp32_row_groups_match_oracle_and_single_rows(ops, device, monke
     cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
     want = orc.varlen_causal_attention(q.numpy(), k.numpy(), v.numpy(), cu, dtype=np.float64)
     args = (q.to(device), k.to(device), v.to(device), torch.from_numpy(cu).to(device), max(lens))
-    default = ops.prefill_causal(*args).cpu().numpy()          # head_dim 32 / 64: one query row per lane
+    default = ops.prefill_causal(*args).cpu().numpy()          # head_dim 32 / 64 / 128: one query row per lane
     monkeypatch.setenv('MI355_PREFILL_F32_TILED', '0')
     grouped = ops.prefill_causal(*args).cpu().numpy()
     monkeypatch.setenv('MI355_PREFILL_ROW_GROUPS', '0')

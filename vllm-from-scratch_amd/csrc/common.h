@@ -41,7 +41,7 @@ int prefill_mfma_paged_launch(void* out, const void* q, int64_t q_stride_tok, co
                               int64_t s_blk, int64_t s_head, int64_t s_tok, float scale, int dtype,
                               hipStream_t stream);
 
-// fp32 causal prefill with one query row per lane (prefill_f32.hip): head_dim 32 / 64.
+// fp32 causal prefill with one query row per lane (prefill_f32.hip): head_dim 32 / 64 / 128.
 bool prefill_f32_supported(int dtype, int D);
 int prefill_f32_launch(void* out, const void* q, const void* k, const void* v, int64_t q_stride_tok,
                        int64_t kv_stride_tok, const int32_t* cu_seqlens, int nseq, int max_seqlen, int Hq, int Hkv,

@@ -829,7 +829,7 @@ extern "C" int mi355_prefill_causal(void* out, const void* q, const void* k, con
       !env_int("MI355_PREFILL_VALU", 0))
     return prefill_mfma_launch(out, q, k, v, q_stride_tok, kv_stride_tok, cu_seqlens, nseq, total_tokens,
                                max_seqlen, Hq, Hkv, D, scale, dtype, static_cast<hipStream_t>(stream));
-  // fp32 at head_dim 32 / 64: one query row per lane, K/V rows broadcast from LDS (prefill_f32.hip).
+  // fp32 at head_dim 32 / 64 / 128: one query row per lane (prefill_f32.hip).
   // MI355_PREFILL_F32_TILED=0 keeps the decode-shaped kernel below (A/B measurements).
   if (prefill_f32_supported(dtype, D) && env_int("MI355_PREFILL_F32_TILED", 1))
     return prefill_f32_launch(out, q, k, v, q_stride_tok, kv_stride_tok, cu_seqlens, nseq, max_seqlen, Hq, Hkv, D,
