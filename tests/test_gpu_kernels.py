@@ -296,6 +296,9 @@ def test_paged_prefill_rejects_unsupported_shapes(ops, device):
     (torch.float32, 4, 4, 32, 16, [(0, 40), (130, 17), (5, 1), (64, 64)]),    # the reference engine's default geometry
     (torch.float32, 8, 2, 64, 8, [(1000, 21), (3, 9)]),                       # grouped heads, long prefix
     (torch.float32, 6, 6, 128, 3, [(10, 29)]),                                # block size not a power of two
+    (torch.float32, 8, 2, 64, 16, [(100, 200), (0, 70), (7, 3)]),             # long chunks
+    (torch.float32, 4, 4, 128, 8, [(31, 100)]),
+    (torch.float32, 4, 2, 32, 3, [(50, 129), (0, 64)]),                       # block size not a power of two
     (torch.bfloat16, 4, 4, 32, 16, [(33, 50), (0, 7)]),                       # 16-bit at a head_dim off the matrix-core path
     (torch.float16, 2, 1, 256, 4, [(20, 30)]),
 ])
