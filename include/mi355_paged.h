@@ -14,7 +14,8 @@
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).
  *    All work is enqueued on it and the call returns without synchronising.
  *  - The library allocates no device memory.  Scratch space comes in through
- *    the `workspace` argument, sized by mi355_paged_decode_workspace_bytes().
+ *    the `workspace` argument, sized by mi355_paged_decode_workspace_bytes()
+ *    (mi355_paged_decode_static keeps its scratch in the library's device image).
  *  - Strides are in ELEMENTS of the tensor's dtype.  Head rows (the innermost
  *    D elements) must be contiguous and 16-byte aligned.
  *  - `dtype`: MI355_F32 = 0, MI355_BF16 = 1, MI355_F16 = 2.  Accumulation is
@@ -24,7 +25,8 @@
  *    the last failure on the calling thread is available from
  *    mi355_last_error().
  *  - Thread safety: the library keeps no mutable global state besides the
- *    thread-local error string; calls may be made from any thread.
+ *    thread-local error string (and the shared scratch array of
+ *    mi355_paged_decode_static, see there); calls may be made from any thread.
  */
 #ifndef MI355_PAGED_H
 #define MI355_PAGED_H
@@ -95,6 +97,31 @@ int mi355_paged_decode(void* out, const void* q, int64_t q_stride_seq,
 /* Scratch bytes mi355_paged_decode needs for this shape (split-KV partials). */
 size_t mi355_paged_decode_workspace_bytes(int32_t B, int32_t Hq, int32_t Hkv, int32_t D,
                                           int32_t block_size, int32_t max_context, int32_t dtype);
+
+/*
+ * mi355_paged_decode without the workspace argument, for callers that cannot allocate device
+ * memory: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ * It has no counterpart in the reference.  Arguments, kernels and results are those of
+ * mi355_paged_decode (bit for bit); the split-KV partials live in an array of
+ * MI355_STATIC_SCRATCH_BYTES that is part of the library's device image, so every GPU the
+ * library runs on holds that much memory until the process ends.  The call performs no
+ * hipMalloc / hipFree; its first split call on a device looks the array's address up once
+ * (hipGetSymbolAddress), with that device current.
+ *   - A shape whose partials (mi355_paged_decode_workspace_bytes) exceed
+ *     MI355_STATIC_SCRATCH_BYTES is rejected with MI355_EWORKSPACE before any launch.
+ *   - All calls on one GPU share the array: calls whose kernels may overlap on that GPU
+ *     (different streams, different threads) race on it.  Calls on one stream are safe, and
+ *     nothing in the array needs clearing between calls: every record a call reads, it wrote.
+ */
+#define MI355_STATIC_SCRATCH_BYTES (16u << 20)
+int mi355_paged_decode_static(void* out, const void* q, int64_t q_stride_seq,
+                              const void* k_cache, const void* v_cache,
+                              const int32_t* block_tables, const int32_t* context_lens,
+                              int32_t B, int32_t Hq, int32_t Hkv, int32_t D,
+                              int32_t block_size, int32_t max_blocks, int32_t num_blocks,
+                              int32_t max_context,
+                              int64_t kv_stride_block, int64_t kv_stride_head, int64_t kv_stride_tok,
+                              float scale, int32_t dtype, void* stream);
 
 /*
  * Scatter T new K/V rows into the paged caches by flat slot id

@@ -21,6 +21,8 @@
 //   second kernel reading fp32 partials from the caller's workspace.
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "common.h"
 #include "decode_params.h"
 
@@ -621,33 +623,37 @@ extern "C" size_t mi355_paged_decode_workspace_bytes(int32_t B, int32_t Hq, int3
   return pl.ws_bytes;
 }
 
-extern "C" int mi355_paged_decode(void* out, const void* q, int64_t q_stride_seq, const void* k_cache,
-                                  const void* v_cache, const int32_t* block_tables,
-                                  const int32_t* context_lens, int32_t B, int32_t Hq, int32_t Hkv,
-                                  int32_t D, int32_t block_size, int32_t max_blocks, int32_t num_blocks,
-                                  int32_t max_context, int64_t kv_stride_block, int64_t kv_stride_head,
-                                  int64_t kv_stride_tok, float scale, int32_t dtype, void* workspace,
-                                  size_t workspace_bytes, void* stream) {
+namespace mi355 {
+namespace {
+
+// Body of mi355_paged_decode; `what` names the entry point in error messages and `ws_limit_what`
+// says where the scratch comes from when it is too small.
+int paged_decode_impl(const char* what, void* out, const void* q, int64_t q_stride_seq, const void* k_cache,
+                      const void* v_cache, const int32_t* block_tables, const int32_t* context_lens, int32_t B,
+                      int32_t Hq, int32_t Hkv, int32_t D, int32_t block_size, int32_t max_blocks,
+                      int32_t num_blocks, int32_t max_context, int64_t kv_stride_block, int64_t kv_stride_head,
+                      int64_t kv_stride_tok, float scale, int32_t dtype, void* workspace, size_t workspace_bytes,
+                      void* stream) {
   if (B == 0) return 0;
   if (!out || !q || !k_cache || !v_cache || !block_tables || !context_lens)
-    return fail(MI355_EINVAL, "paged_decode: null pointer argument");
-  if (max_blocks <= 0 || num_blocks <= 0) return fail(MI355_EINVAL, "paged_decode: max_blocks/num_blocks");
+    return fail(MI355_EINVAL, "%s: null pointer argument", what);
+  if (max_blocks <= 0 || num_blocks <= 0) return fail(MI355_EINVAL, "%s: max_blocks/num_blocks", what);
   if ((int64_t)max_context > (int64_t)max_blocks * block_size) max_context = max_blocks * block_size;
   DecodePlan pl;
   if (int rc = make_plan(B, Hq, Hkv, D, block_size, max_context, dtype, &pl)) return rc;
   const int epl = elems_per_lane(dtype);
-  const int64_t esz = dtype == MI355_F32 ? 4 : 2;
   if (kv_stride_block <= 0 || kv_stride_head < 0 || kv_stride_tok <= 0 || kv_stride_block >= (1LL << 31) ||
       kv_stride_tok >= (1LL << 31) || (int64_t)Hkv * kv_stride_head + D >= (1LL << 31))
-    return fail(MI355_EINVAL, "paged_decode: kv strides out of range");
+    return fail(MI355_EINVAL, "%s: kv strides out of range", what);
   if (kv_stride_block % epl || kv_stride_head % epl || kv_stride_tok % epl || q_stride_seq % epl ||
       q_stride_seq < (int64_t)Hq * D)
-    return fail(MI355_EINVAL, "paged_decode: strides must keep head rows 16-byte aligned");
+    return fail(MI355_EINVAL, "%s: strides must keep head rows 16-byte aligned", what);
   if (((uintptr_t)out | (uintptr_t)q | (uintptr_t)k_cache | (uintptr_t)v_cache) & 15)
-    return fail(MI355_EINVAL, "paged_decode: tensors must be 16-byte aligned");
-  (void)esz;
+    return fail(MI355_EINVAL, "%s: tensors must be 16-byte aligned", what);
+  if ((int64_t)B * pl.nsplit * pl.hgroups * pl.qchunks >= (1LL << 31) || (int64_t)B * Hq >= (1LL << 31))
+    return fail(MI355_EINVAL, "%s: grid too large (B %d)", what, B);
   if (pl.ws_bytes && (!workspace || workspace_bytes < pl.ws_bytes || ((uintptr_t)workspace & 15)))
-    return fail(MI355_EWORKSPACE, "paged_decode: need %zu workspace bytes (16-B aligned), got %zu",
+    return fail(MI355_EWORKSPACE, "%s: need %zu workspace bytes (16-B aligned), got %zu", what,
                 pl.ws_bytes, workspace ? workspace_bytes : (size_t)0);
 
   DecodeParams p;
@@ -691,7 +697,82 @@ extern "C" int mi355_paged_decode(void* out, const void* q, int64_t q_stride_seq
     case MI355_BF16: return dispatch_d<BF16>(D, p, pl, s);
     case MI355_F16: return dispatch_d<F16>(D, p, pl, s);
   }
-  return fail(MI355_EINVAL, "paged_decode: dtype %d", dtype);
+  return fail(MI355_EINVAL, "%s: dtype %d", what, dtype);
+}
+
+// Split-KV partials of mi355_paged_decode_static: one array per GPU, held until the process ends.
+// The name below is only a host-side handle; kernels get the per-device address that
+// hipGetSymbolAddress reports.
+static __device__ __align__(256) unsigned char scratch[MI355_STATIC_SCRATCH_BYTES];
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+void* g_scratch_ptr[kMaxDevices];   // device address of `scratch` on each GPU, filled on first use
+
+// Address of `scratch` on the current device (looked up once per device), or nullptr + error.
+void* static_scratch(int* rc) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+    *rc = fail(e != hipSuccess ? (int)e : MI355_EUNSUPPORTED, "paged_decode_static: device %d (%s)", dev,
+               hipGetErrorString(e));
+    return nullptr;
+  }
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void* ptr = nullptr;
+    e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr) {
+      *rc = fail(e != hipSuccess ? (int)e : MI355_EUNSUPPORTED,
+                 "paged_decode_static: hipGetSymbolAddress on device %d: %s", dev, hipGetErrorString(e));
+      return nullptr;
+    }
+    g_scratch_ptr[dev] = ptr;
+  }
+  return g_scratch_ptr[dev];
+}
+
+}  // namespace
+}  // namespace mi355
+
+extern "C" int mi355_paged_decode(void* out, const void* q, int64_t q_stride_seq, const void* k_cache,
+                                  const void* v_cache, const int32_t* block_tables,
+                                  const int32_t* context_lens, int32_t B, int32_t Hq, int32_t Hkv,
+                                  int32_t D, int32_t block_size, int32_t max_blocks, int32_t num_blocks,
+                                  int32_t max_context, int64_t kv_stride_block, int64_t kv_stride_head,
+                                  int64_t kv_stride_tok, float scale, int32_t dtype, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  return paged_decode_impl("paged_decode", out, q, q_stride_seq, k_cache, v_cache, block_tables, context_lens, B, Hq,
+                           Hkv, D, block_size, max_blocks, num_blocks, max_context, kv_stride_block, kv_stride_head,
+                           kv_stride_tok, scale, dtype, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mi355_paged_decode_static(void* out, const void* q, int64_t q_stride_seq, const void* k_cache,
+                                         const void* v_cache, const int32_t* block_tables,
+                                         const int32_t* context_lens, int32_t B, int32_t Hq, int32_t Hkv,
+                                         int32_t D, int32_t block_size, int32_t max_blocks, int32_t num_blocks,
+                                         int32_t max_context, int64_t kv_stride_block, int64_t kv_stride_head,
+                                         int64_t kv_stride_tok, float scale, int32_t dtype, void* stream) {
+  if (B == 0) return 0;
+  if (max_blocks > 0 && block_size > 0 && (int64_t)max_context > (int64_t)max_blocks * block_size)
+    max_context = max_blocks * block_size;   // the plan is made for the clamped context, as in the body
+  DecodePlan pl;
+  if (int rc = make_plan(B, Hq, Hkv, D, block_size, max_context, dtype, &pl)) return rc;
+  if (pl.ws_bytes > (size_t)MI355_STATIC_SCRATCH_BYTES)
+    return fail(MI355_EWORKSPACE,
+                "paged_decode_static: this shape needs %zu bytes of split-KV partials, the built-in scratch holds %zu; "
+                "use mi355_paged_decode with a caller workspace",
+                pl.ws_bytes, (size_t)MI355_STATIC_SCRATCH_BYTES);
+  void* ptr = nullptr;
+  if (pl.ws_bytes) {   // unsplit shapes never touch the array
+    int rc = 0;
+    ptr = static_scratch(&rc);
+    if (!ptr) return rc;
+  }
+  return paged_decode_impl("paged_decode_static", out, q, q_stride_seq, k_cache, v_cache, block_tables, context_lens,
+                           B, Hq, Hkv, D, block_size, max_blocks, num_blocks, max_context, kv_stride_block,
+                           kv_stride_head, kv_stride_tok, scale, dtype, ptr, ptr ? (size_t)MI355_STATIC_SCRATCH_BYTES : 0,
+                           stream);
 }
 
 extern "C" int mi355_paged_prefill(void* out, const void* q, int64_t q_stride_tok, const void* k_cache,
