@@ -12,21 +12,25 @@ One step = one decode step of one attention layer for the whole batch:
   (1) write the new token's K/V rows into their slots   (mi355_kv_write_slots)
   (2) paged decode attention over the 2048-token context (mi355_paged_decode)
   (3) greedy sampling from fp32 logits [256, 32000]      (mi355_sample_argmax)
-  (4) with N > 1: all-gather of the sampled ids across ranks (RCCL), asynchronous: ranks do
-      not need each other's ids to go on decoding, so a collective overlaps the steps after it.
-      The ids of --gather-every consecutive steps (default 4) travel in one collective: its
-      fixed cost (about 26 us per call measured on a one-rank communicator, mostly the two
-      stream dependencies around it) would otherwise be a seventh of a 182 us step.  Every id
-      is exchanged, and every collective has completed, before the timed region closes
-`value` = sequences (= tokens) decoded per second over all ranks.  `roofline`
-prices step (2), the dominant kernel, against HBM bandwidth using the
-algorithmic byte count and the average of HIP-event-bracketed launches inside
-the timed region (every 4th step, see EVENT_EVERY); `cpu_baseline` times the reference-shaped CPU decode
-(oracle/loop_form.py) on a bounded sample of the same sequences.
+  (4) with N > 1: all-gather of the sampled ids across ranks (RCCL), one collective per step,
+      asynchronous: ranks do not need each other's ids to go on decoding, so a collective
+      overlaps the steps after it.  --gather-every k (not the default) sends the ids of k
+      consecutive steps in one collective and says so in `config.workload`.  Every id is
+      exchanged, and every collective has completed, before the timed region closes.
+`value` = sequences (= tokens) decoded per second over all ranks; the timed region holds exactly
+--steps steps and no instrumentation.  `roofline` prices step (2), the dominant kernel, against
+HBM bandwidth: algorithmic bytes / the average of ROOFLINE_LAUNCHES launches, each between two
+HIP events on the launch stream, in a loop of the same steps that runs right after the timed
+region (so its size does not depend on --steps and its events cost the tokens/s figure nothing).
+`roofline.traffic` is the counter-measured HBM bytes per launch from the newest
+profiles/*_pmc_traffic.json, reported only when that file was collected with the very library
+this process loaded (sha256 match), else null with a `traffic_stale` note.  `cpu_baseline` times
+the reference-shaped CPU decode (oracle/loop_form.py) on a bounded sample of the same sequences.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -77,7 +81,7 @@ def build_inputs(cfg, device, seed, sets=2):
     return dict(pools=pools, q=q, k_new=k_new, v_new=v_new, ctx=ctx, logits=logits, slots=slots)
 
 
-def cpu_baseline(cfg, inp, budget_s=12.0, max_seqs=256):
+def cpu_baseline(cfg, inp, budget_s=4.0, max_seqs=256):
     """Reference-shaped CPU decode on a sample of the benchmark's own sequences (fp32, as the
     reference runs it).  Returns the JSON object for the bench line."""
     from oracle import loop_form, paged_oracle
@@ -111,10 +115,34 @@ def cpu_baseline(cfg, inp, budget_s=12.0, max_seqs=256):
             "vectorised_numpy_ms_per_sequence": round(1e3 * vdt, 2)}
 
 
-# HIP events bracket the decode launch of every n-th timed step: a pair of event records costs
-# about 4 us of stream time (the kernels around it no longer dispatch back to back), which on
-# every step is 2.4 % of the step.  BENCH_EVENT_EVERY=1 brackets every launch.
-EVENT_EVERY = max(1, int(os.environ.get('BENCH_EVENT_EVERY', '4')))
+# Launches of the dominant kernel timed between HIP events after the tokens/s region.
+ROOFLINE_LAUNCHES = max(8, int(os.environ.get('BENCH_ROOFLINE_LAUNCHES', '64')))
+
+
+def library_sha256():
+    from mi355_paged import _lib
+    h = hashlib.sha256()
+    with open(_lib.LIB_PATH, 'rb') as f:
+        for chunk in iter(lambda: f.read(1 << 20), b''):
+            h.update(chunk)
+    return h.hexdigest()
+
+
+def measured_traffic(config_name, lib_hash):
+    """(bytes per launch or None, note) from the newest committed counter digest of this config
+    that was collected with the library now loaded."""
+    import glob
+    suffix = '_pmc_traffic.json' if config_name == 'metric' else f'_pmc_traffic_{config_name}.json'
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*' + suffix)), key=os.path.getmtime)
+    if not files:
+        return None, {"traffic_stale": f"no profiles/*{suffix}"}
+    with open(files[-1]) as f:
+        digest = json.load(f)
+    rel = os.path.relpath(files[-1], ROOT)
+    if digest.get("library_sha256") != lib_hash:
+        return None, {"traffic_stale": f"{rel} was collected with another build of the library "
+                                       f"({str(digest.get('library_sha256'))[:12]} vs loaded {lib_hash[:12]})"}
+    return digest.get("hbm_bytes_per_launch"), {"traffic_source": rel}
 
 
 def main():
@@ -124,8 +152,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--config', default='metric', choices=sorted(CONFIGS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--gather-every', type=int, default=4,
-                    help='steps whose sampled ids share one all-gather (N > 1); every id is exchanged inside the timed region')
+    ap.add_argument('--gather-every', type=int, default=1,
+                    help='steps whose sampled ids share one all-gather (N > 1; 1 = one collective per step, the '
+                         'specified workload); every id is exchanged inside the timed region')
     args = ap.parse_args()
     # Keep stdout for the one JSON line: whatever libraries print on file descriptor 1 while the
     # job runs (the collective library prints a version banner there when its communicator comes
@@ -175,19 +204,23 @@ def main():
     gather = dp.OverlappedTokenGather(B, device, single_rank_collective=use_dist, every=args.gather_every,
                                       native=native)
 
-    ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    roofline_ids = torch.empty((B,), dtype=torch.int32, device=device)
+    ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(ROOFLINE_LAUNCHES)]
+    ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(ROOFLINE_LAUNCHES)]
 
-    def step(i, timed):
+    def step(i, bracket=None):
         kc, vc, bt = inp['pools'][i % nsets]
         ops.kv_write_slots(kc, vc, inp['k_new'], inp['v_new'], inp['slots'][i % nsets], 'NHSD')
-        if timed and i % EVENT_EVERY == 0:
-            ev_a[i].record()
+        if bracket is not None:
+            ev_a[bracket].record()
         ops.paged_decode(inp['q'], kc, vc, bt, inp['ctx'], S, layout='NHSD', out=out)
-        if timed and i % EVENT_EVERY == 0:
-            ev_b[i].record()
-        ops.sample_argmax(inp['logits'], out=gather.send_buffer(i))
-        gather.launch(i)
+        if bracket is not None:
+            ev_b[bracket].record()
+        if bracket is None:
+            ops.sample_argmax(inp['logits'], out=gather.send_buffer(i))
+            gather.launch(i)
+        else:
+            ops.sample_argmax(inp['logits'], out=roofline_ids)
 
     def barrier():
         if use_dist:
@@ -196,14 +229,14 @@ def main():
 
     trace('inputs built')
     for i in range(args.warmup):
-        step(i, False)
+        step(i)
     gather.drain()
     trace('warmup issued')
     barrier()
     trace('timed region')
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i, True)
+        step(i)
     gather.drain()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -213,12 +246,25 @@ def main():
         elapsed = float(t.item())
     assert gather.result(args.steps - 1).numel() == B * world
 
-    kernel_ms = sorted(ev_a[i].elapsed_time(ev_b[i]) for i in range(0, args.steps, EVENT_EVERY))
-    avg_ms = sum(kernel_ms) / len(kernel_ms)
+    # Roofline loop (outside `value`): the same steps, the decode launch of each between two HIP
+    # events on the launch stream (torch's current stream, the one ops passes to the library).  A
+    # spin kernel holds the stream for a few milliseconds first so that the host has queued the
+    # launches before the device reaches them: an event pair then spans the device-side cost of the
+    # launch (dispatch + kernel), not the host's call overhead, whatever the step's length.
+    if rank == 0:
+        torch.cuda._sleep(8_000_000)
+        for j in range(ROOFLINE_LAUNCHES):
+            step(args.steps + j, bracket=j)
+        torch.cuda.synchronize()
+        kernel_ms = sorted(ev_a[j].elapsed_time(ev_b[j]) for j in range(ROOFLINE_LAUNCHES))
+        avg_ms = sum(kernel_ms) / len(kernel_ms)
+    if use_dist:
+        dist.barrier()
     abytes = algorithmic_bytes(B, S, H, H, D, BS, 2)
-    achieved = abytes / (avg_ms * 1e-3) / 1e9
 
     if rank == 0:
+        achieved = abytes / (avg_ms * 1e-3) / 1e9
+        lib_hash = library_sha256()
         line = {
             "metric": "decode tokens/sec + achieved HBM GB/s, block_size=16 batch=256 seq=2048"
                       if args.config == 'metric' else f"decode tokens/sec ({args.config})",
@@ -231,7 +277,9 @@ def main():
             "config": {"workload": f"paged decode step: batch={B}/GPU, ctx={S}, heads={H}, head_dim={D}, "
                                    f"block_size={BS}, bf16 KV [blocks,heads,{BS},{D}], scattered block table; "
                                    f"kv-write + paged attention + greedy argmax(vocab={cfg['vocab']})"
-                                   + (f" + RCCL all-gather of ids (one collective per {args.gather_every} steps)" if use_dist else ""),
+                                   + (" + RCCL all-gather of ids, one collective per step" if use_dist and args.gather_every == 1
+                                      else f" + RCCL all-gather of ids, BATCHED: one collective per {args.gather_every} steps"
+                                      if use_dist else ""),
                        "batch_per_gpu": B, "context": S, "block_size": BS, "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
@@ -240,16 +288,15 @@ def main():
                          "avg_launch_ms": round(avg_ms, 5), "launches_timed": len(kernel_ms),
                          "p10_ms": round(kernel_ms[len(kernel_ms) // 10], 5),
                          "p50_ms": round(kernel_ms[len(kernel_ms) // 2], 5),
-                         "p90_ms": round(kernel_ms[(len(kernel_ms) * 9) // 10], 5)},
+                         "p90_ms": round(kernel_ms[(len(kernel_ms) * 9) // 10], 5),
+                         "timing": "HIP events around each launch, in a loop of the same steps after the timed region"},
+            "library_sha256": lib_hash,
         }
         # HBM bytes per launch from the committed counter passes (tools/collect_profiles.sh +
-        # tools/pmc_traffic.py; counters cannot be read inside this process); newest file wins
-        import glob
-        traffic_files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')))
-        if args.config == 'metric' and traffic_files:
-            with open(traffic_files[-1]) as f:
-                line["roofline"]["traffic"] = json.load(f).get("hbm_bytes_per_launch")
-            line["roofline"]["traffic_source"] = os.path.relpath(traffic_files[-1], ROOT)
+        # tools/pmc_traffic.py; counters cannot be read inside this process)
+        traffic, note = measured_traffic(args.config, lib_hash)
+        line["roofline"]["traffic"] = traffic
+        line["roofline"].update(note)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, inp)
         sys.stdout.flush()

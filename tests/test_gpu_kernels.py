@@ -421,6 +421,56 @@ def test_decode_metric_shape_subset_bf16(ops, device):
     np.testing.assert_allclose(out2.float().cpu().numpy()[0], out[3], **LOWP_TOL)
 
 
+@pytest.mark.parametrize('layout', ['NHSD', 'NSHD'])
+def test_decode_config2_all_rows_bf16(ops, device, layout):
+    """The single-GPU configuration B=64, S=1024, 8 heads, D=64, BS=16, bf16, scattered block table.
+    Its launch plan differs from the benchmark shape's (fewer kv heads per workgroup, the freed
+    waves take token sub-ranges of a head and merge through LDS), so the exact workload is checked:
+    every row against the float64 oracle on the rounded inputs, plus batch-order equivariance
+    (bit for bit) and invariance under moving a sequence's blocks, in both cache layouts."""
+    B, S, H, D, BS = 64, 1024, 8, 64, 16
+    per = S // BS
+    g = torch.Generator(device='cpu').manual_seed(2)
+    NB = B * per + 64
+    kc = torch.randn((NB, H, BS, D), generator=g, dtype=torch.float32).to(torch.bfloat16)
+    vc = torch.randn((NB, H, BS, D), generator=g, dtype=torch.float32).to(torch.bfloat16)
+    q = torch.randn((B, H, D), generator=g, dtype=torch.float32).to(torch.bfloat16)
+    bt = torch.randperm(NB, generator=g)[:B * per].view(B, per).to(torch.int32)
+    ctx = torch.full((B,), S, dtype=torch.int32)
+
+    def dev_cache(t):
+        t = t.to(device)
+        return t.permute(0, 2, 1, 3).contiguous() if layout == 'NSHD' else t
+
+    kd, vd = dev_cache(kc), dev_cache(vc)
+    out_t = ops.paged_decode(q.to(device), kd, vd, bt.to(device), ctx.to(device), S, layout=layout)
+    torch.cuda.synchronize()
+    out = out_t.float().cpu().numpy()
+    want = orc.paged_decode_batch(q.float().numpy(), kc.float().numpy(), vc.float().numpy(), bt.numpy(),
+                                  [S] * B, BS, dtype=np.float64)
+    np.testing.assert_allclose(out, want, **LOWP_TOL)
+    # a permuted batch gives permuted rows, bit for bit
+    perm = torch.randperm(B, generator=g)
+    out_perm = ops.paged_decode(q[perm].to(device), kd, vd, bt[perm].to(device), ctx.to(device), S, layout=layout)
+    assert torch.equal(out_perm.cpu(), out_t.cpu()[perm])
+    # moving the blocks of sequence 5 into the spare blocks of the pool changes nothing, bit for bit
+    used = set(bt.flatten().tolist())
+    spare = torch.tensor([i for i in range(NB) if i not in used][:per])
+    kc2, vc2, bt2 = kc.clone(), vc.clone(), bt.clone()
+    kc2[spare] = kc[bt[5].long()]
+    vc2[spare] = vc[bt[5].long()]
+    bt2[5] = spare.to(torch.int32)
+    out2 = ops.paged_decode(q.to(device), dev_cache(kc2), dev_cache(vc2), bt2.to(device), ctx.to(device), S,
+                            layout=layout)
+    assert torch.equal(out2.cpu(), out_t.cpu())
+    # ragged contexts at the same batch and bound: rows again equal the oracle
+    rctx = torch.randint(1, S + 1, (B,), generator=g, dtype=torch.int32)
+    out3 = ops.paged_decode(q.to(device), kd, vd, bt.to(device), rctx.to(device), S, layout=layout)
+    want3 = orc.paged_decode_batch(q.float().numpy(), kc.float().numpy(), vc.float().numpy(), bt.numpy(),
+                                   rctx.tolist(), BS, dtype=np.float64)
+    np.testing.assert_allclose(out3.float().cpu().numpy(), want3, **LOWP_TOL)
+
+
 def test_decode_grouped_query_large_shape_properties(ops, device):
     """A serving-size grouped-query batch (64 sequences x 4096 tokens, 32 query / 8 kv heads,
     D=128, bf16; 1 GiB of KV) through the matrix-core kernel: a subset of rows against the

@@ -104,6 +104,23 @@ __global__ void __launch_bounds__(kMaxThreads) paged_decode_kernel(const DecodeP
 
   auto block_of = [&](int t) { return p.bs_shift >= 0 ? (t >> p.bs_shift) : (t / p.block_size); };
 
+  const int hslot = wave % p.hpw, sb = wave / p.hpw;
+  const int kvh = hg * p.hpw + hslot;
+  const int tl = lane / LPT, dg = lane % LPT;
+
+  // Query fragments: this lane's EPL dims of each of the G query heads.  Their loads are issued
+  // before the block table is staged, so both round trips to memory overlap.
+  const int hq0 = ROWS ? kvh * p.gq + qc : kvh * p.gq + qc * G;
+  u32x4 qraw[G];
+#pragma unroll
+  for (int gi = 0; gi < G; ++gi) {
+    const int hq = ROWS ? hq0 : (qc * G + gi < p.gq) ? hq0 + gi : hq0;
+    const int qrow = ROWS ? row0 + min(gi, nrows - 1) : b;
+    const char* src = static_cast<const char*>(p.q) +
+                      ((int64_t)qrow * p.q_stride_seq + (int64_t)hq * D + dg * EPL) * Tag::kBytes;
+    qraw[gi] = load16<false>(src);
+  }
+
   // Stage this split's slice of the block table in LDS (ids clamped for memory safety).
   const int lb0 = block_of(t0);
   const int nlb = (wg_end > t0 && !p.cu) ? block_of(wg_end - 1) - lb0 + 1 : 0;
@@ -113,25 +130,14 @@ __global__ void __launch_bounds__(kMaxThreads) paged_decode_kernel(const DecodeP
   }
   __syncthreads();
 
-  const int hslot = wave % p.hpw, sb = wave / p.hpw;
-  const int kvh = hg * p.hpw + hslot;
   // ROWS: the group's own context is shared out between the sub-range waves (early groups are short)
   const int len_w = ROWS ? (ctx + p.sub * TS - 1) / (p.sub * TS) * TS : p.tps / p.sub;
   const int tw0 = t0 + sb * len_w;
   const int tw1 = min(wg_end, tw0 + len_w);
-  const int tl = lane / LPT, dg = lane % LPT;
 
-  // Query fragments: this lane's EPL dims of each of the G query heads.
-  const int hq0 = ROWS ? kvh * p.gq + qc : kvh * p.gq + qc * G;
   typename Tag::QFrag qf[G];
 #pragma unroll
-  for (int gi = 0; gi < G; ++gi) {
-    const int hq = ROWS ? hq0 : (qc * G + gi < p.gq) ? hq0 + gi : hq0;
-    const int qrow = ROWS ? row0 + min(gi, nrows - 1) : b;
-    const char* src = static_cast<const char*>(p.q) +
-                      ((int64_t)qrow * p.q_stride_seq + (int64_t)hq * D + dg * EPL) * Tag::kBytes;
-    qf[gi] = Tag::make_q(load16<false>(src));
-  }
+  for (int gi = 0; gi < G; ++gi) qf[gi] = Tag::make_q(qraw[gi]);
 
   float m[G], l[G], acc[G][EPL];
 #pragma unroll
