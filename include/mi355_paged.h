@@ -333,6 +333,19 @@ int mi355_dp_init(const void* id, int32_t nranks, int32_t rank, void** comm_out)
 int mi355_dp_allgather_i32(void* comm, const int32_t* send, int32_t* recv, int64_t count, void* stream);
 int mi355_dp_destroy(void* comm);
 
+/*
+ * Debugging / measurement aid, not part of the replaced path (no counterpart in the reference).
+ * The launch plans have a few integer knobs kept switchable so that two variants can be compared
+ * inside one process: MI355_DECODE_GQA_MFMA, MI355_PAGED_TARGET_WGS, MI355_PAGED_HPW,
+ * MI355_PAGED_PREFILL_MIN_Q, MI355_PREFILL_VALU, MI355_PREFILL_F32_TILED, MI355_PREFILL_ROW_GROUPS,
+ * MI355_PREFILL_WAVES, MI355_MLA_MANY_HEADS, MI355_MLA_TARGET_WGS.  Each takes its default, or the
+ * value of the environment variable of the same name, which the library reads ONCE per process;
+ * afterwards only this call changes it (value INT32_MIN restores the process's start-up value).
+ * Returns MI355_EINVAL for an unknown name.  A knob must not change between a workspace-size
+ * query and the launch it sizes.
+ */
+int mi355_debug_set_knob(const char* name, int32_t value);
+
 #ifdef __cplusplus
 }
 #endif

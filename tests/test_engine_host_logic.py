@@ -272,3 +272,18 @@ def test_plan_later_chunks_become_append_segments_when_the_kernel_covers_the_mod
     rows = build_attn_plan(*args)
     assert rows.append_tokens == 0 and _rows(rows.paged_index) == [0, 1, 2, 3, 6]
     assert rows.paged_context.tolist() == [8, 5, 6, 7, 10]
+    # a per-segment rule: contexts the table-staging kernels cannot hold fall back to rows
+    limited = build_attn_plan(*args, append_ok=lambda n_q, context: context <= 6)
+    assert limited.append_tokens == 0 and _rows(limited.paged_index) == [0, 1, 2, 3, 6]
+    assert build_attn_plan(*args, append_ok=lambda n_q, context: context <= 7).append_tokens == 3
+
+
+def test_paged_prefill_serves_rule():
+    import torch
+    from mi355_paged import ops
+    limit = ops.PAGED_PREFILL_STAGED_BLOCKS * 16
+    assert ops.paged_prefill_serves(torch.float32, 32, 16, 8, limit)
+    assert not ops.paged_prefill_serves(torch.float32, 32, 16, 8, limit + 1)        # VALU kernel stages the table
+    assert not ops.paged_prefill_serves(torch.bfloat16, 64, 16, 47, limit + 1)      # short chunk: append kernel, staged
+    assert ops.paged_prefill_serves(torch.bfloat16, 64, 16, 48, 10 * limit)         # flash kernel reads the table itself
+    assert not ops.paged_prefill_serves(torch.bfloat16, 48, 16, 48, 100)            # head_dim without a kernel

@@ -152,8 +152,8 @@ def test_decode_grouped_query_matrix_core(ops, device, shape, dtype, layout):
     np.testing.assert_allclose(out, want, **LOWP_TOL)
 
 
-def test_decode_grouped_query_matches_valu_kernel(ops, device, monkeypatch):
-    """Same inputs through the matrix-core kernel and (MI355_DECODE_GQA_MFMA=0) the VALU kernel:
+def test_decode_grouped_query_matches_valu_kernel(ops, device):
+    """Same inputs through the matrix-core kernel and (knob MI355_DECODE_GQA_MFMA = 0) the VALU kernel:
     both within tolerance of the oracle and of each other; zero-length rows give zeros in both."""
     rng = np.random.default_rng(77)
     B, Hq, Hkv, D, BS, max_ctx = 6, 32, 4, 128, 16, 400
@@ -162,8 +162,8 @@ def test_decode_grouped_query_matches_valu_kernel(ops, device, monkeypatch):
     q = torch.from_numpy(q).to(torch.bfloat16).float().numpy()
     cache = torch.from_numpy(cache).to(torch.bfloat16).float().numpy()
     mfma = _decode_on_gpu(ops, device, q, cache, bt, ctx, torch.bfloat16)
-    monkeypatch.setenv('MI355_DECODE_GQA_MFMA', '0')
-    valu = _decode_on_gpu(ops, device, q, cache, bt, ctx, torch.bfloat16)
+    with ops.debug_knob('MI355_DECODE_GQA_MFMA', 0):
+        valu = _decode_on_gpu(ops, device, q, cache, bt, ctx, torch.bfloat16)
     np.testing.assert_allclose(mfma, valu, **LOWP_TOL)
     assert not mfma[2].any() and not valu[2].any()
     keep = [i for i in range(B) if ctx[i] > 0]
@@ -227,13 +227,18 @@ def test_paged_prefill_segments(ops, device, shape, dtype, layout):
     assert (got[~owned] == 7.0).all()                                 # rows outside every segment are untouched
 
 
-@pytest.mark.parametrize('waves', ['4', '8'])
-def test_paged_prefill_long_chunk_matches_packed_prefill(ops, device, monkeypatch, waves):
+@pytest.fixture
+def prefill_waves(ops, request):
+    with ops.debug_knob('MI355_PREFILL_WAVES', int(request.param)):
+        yield request.param
+
+
+@pytest.mark.parametrize('prefill_waves', ['4', '8'], indirect=True)
+def test_paged_prefill_long_chunk_matches_packed_prefill(ops, device, prefill_waves):
     """A whole prompt presented as one chunk over the paged cache (no prefix) must equal causal
     prompt attention over the same K/V rows; with a prefix, the oracle row by row on a sample.
     Both workgroup widths of the kernel."""
-    monkeypatch.setenv('MI355_PREFILL_WAVES', waves)
-    rng = np.random.default_rng(int(waves))
+    rng = np.random.default_rng(int(prefill_waves))
     Hq, Hkv, D, BS, n = 8, 4, 128, 16, 700
     per = (n + 333 + BS - 1) // BS
     NB = 2 * per + 3
@@ -278,6 +283,34 @@ def test_paged_prefill_clamps_bad_block_ids(ops, device):
     torch.cuda.synchronize()
     assert torch.equal(got[n:], good[n:])
     assert torch.isfinite(got.float()).all()
+
+
+@pytest.mark.parametrize('n', [100, 20])         # flash-attention kernel (>= 48 query tokens) and the append kernel
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_paged_prefill_survives_poisoned_segments(ops, device, n, dtype):
+    """Segment descriptors that contradict the host-side bounds (a start position far past the
+    table, a negative one, a length beyond max_q_len) must neither fault nor disturb the healthy
+    segment: no key at or past max_context is read in any of the three back ends."""
+    rng = np.random.default_rng(n)
+    Hq, D, BS = 4, 64, 16
+    per = (n + BS - 1) // BS
+    NB = 3 * per
+    bt = rng.permutation(NB).reshape(3, per).astype(np.int32)
+    cache = torch.from_numpy(rng.standard_normal((2, NB, Hq, BS, D), dtype=np.float32)).to(dtype).to(device)
+    q = torch.from_numpy(rng.standard_normal((3 * n, Hq, D), dtype=np.float32)).to(dtype).to(device)
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=device)
+    tables = torch.from_numpy(bt).to(device)
+    good = ops.paged_prefill(q, cache[0], cache[1], tables, i32([0, n, 2 * n]), i32([n, n, n]), i32([0, 0, 0]),
+                             n, n).clone()
+    got = ops.paged_prefill(q, cache[0], cache[1], tables, i32([0, n, 2 * n]), i32([n, n, n]),
+                            i32([10 ** 9, 0, -7]), n, n)
+    torch.cuda.synchronize()
+    assert torch.equal(got[n:2 * n], good[n:2 * n])
+    got = ops.paged_prefill(q, cache[0], cache[1], tables, i32([0, n, 2 * n]), i32([n, n, 10 ** 6]),
+                            i32([n // 2, 0, 0]), n, n)
+    torch.cuda.synchronize()
+    assert torch.equal(got[n:2 * n], good[n:2 * n])
+    assert torch.equal(got[2 * n:], good[2 * n:])     # rows past max_q_len do not exist: the segment's n rows are as before
 
 
 def test_paged_prefill_rejects_unsupported_shapes(ops, device):
@@ -600,7 +633,7 @@ def test_prefill_varlen_packed(ops, device, dtype):
     (6, 6, 128, [17, 300]),                     # six kv heads: two per workgroup, waves split the keys
     (3, 1, 256, [40, 9]),
 ])
-def test_prefill_fp32_row_groups_match_oracle_and_single_rows(ops, device, monkeypatch, shape):
+def test_prefill_fp32_row_groups_match_oracle_and_single_rows(ops, device, shape):
     """fp32 prompts: one query row per lane at head_dim 32 / 64 / 128, elsewhere the decode-shaped kernel with
     eight consecutive query rows per wave sharing each K/V load; both meet the oracle and the
     one-row-per-workgroup form of the decode-shaped kernel."""
@@ -612,10 +645,10 @@ def test_prefill_fp32_row_groups_match_oracle_and_single_rows(ops, device, monke
     want = orc.varlen_causal_attention(q.numpy(), k.numpy(), v.numpy(), cu, dtype=np.float64)
     args = (q.to(device), k.to(device), v.to(device), torch.from_numpy(cu).to(device), max(lens))
     default = ops.prefill_causal(*args).cpu().numpy()          # head_dim 32 / 64 / 128: one query row per lane
-    monkeypatch.setenv('MI355_PREFILL_F32_TILED', '0')
-    grouped = ops.prefill_causal(*args).cpu().numpy()
-    monkeypatch.setenv('MI355_PREFILL_ROW_GROUPS', '0')
-    single = ops.prefill_causal(*args).cpu().numpy()
+    with ops.debug_knob('MI355_PREFILL_F32_TILED', 0):
+        grouped = ops.prefill_causal(*args).cpu().numpy()
+        with ops.debug_knob('MI355_PREFILL_ROW_GROUPS', 0):
+            single = ops.prefill_causal(*args).cpu().numpy()
     for got in (default, grouped, single):
         np.testing.assert_allclose(got, want, **F32_TOL)
     np.testing.assert_allclose(grouped, single, atol=2e-6, rtol=1e-5)
@@ -684,12 +717,9 @@ def test_prefill_matrix_core_kernel(ops, device, shape, dtype):
     out = ops.prefill_causal(*args)
     torch.cuda.synchronize()
     np.testing.assert_allclose(out.float().cpu().numpy(), want, **LOWP_TOL)
-    os.environ['MI355_PREFILL_VALU'] = '1'
-    try:
+    with ops.debug_knob('MI355_PREFILL_VALU', 1):
         ref = ops.prefill_causal(*args)
         torch.cuda.synchronize()
-    finally:
-        del os.environ['MI355_PREFILL_VALU']
     np.testing.assert_allclose(ref.float().cpu().numpy(), want, **LOWP_TOL)
     np.testing.assert_allclose(out.float().cpu().numpy(), ref.float().cpu().numpy(), atol=2e-2, rtol=3e-2)
 

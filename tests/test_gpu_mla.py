@@ -67,9 +67,9 @@ def test_mla_decode_config4_shape(ops, device):
     np.testing.assert_allclose(out.cpu().numpy(), want, **TOL[torch.bfloat16])
 
 
-def test_mla_many_heads_kernel_matches_16_head_kernel(ops, device, monkeypatch):
+def test_mla_many_heads_kernel_matches_16_head_kernel(ops, device):
     """128 heads over a split context: the kernel that gives each wave its own 16 heads and the one
-    that runs a workgroup per 16 heads (MI355_MLA_MANY_HEADS=0) agree within tolerance, and both
+    that runs a workgroup per 16 heads (knob MI355_MLA_MANY_HEADS = 0) agree within tolerance, and both
     with the oracle on a sample of heads."""
     rng = np.random.default_rng(12)
     seqs, H, R, P, S = 3, 128, 512, 64, 2500
@@ -81,8 +81,8 @@ def test_mla_many_heads_kernel_matches_16_head_kernel(ops, device, monkeypatch):
     args = (q.to(device), c_kv.to(device), k_rope.to(device), torch.from_numpy(cos).to(device),
             torch.from_numpy(sin).to(device), torch.from_numpy(ctx).to(device), S, 0.07)
     many = ops.mla_decode(*args).cpu().numpy()
-    monkeypatch.setenv('MI355_MLA_MANY_HEADS', '0')
-    tiled = ops.mla_decode(*args).cpu().numpy()
+    with ops.debug_knob('MI355_MLA_MANY_HEADS', 0):
+        tiled = ops.mla_decode(*args).cpu().numpy()
     np.testing.assert_allclose(many, tiled, **TOL[torch.bfloat16])
     heads = [0, 15, 16, 63, 64, 127]
     want = mo.latent_attention(q[:, heads].float().numpy(), c_kv.float().numpy(), k_rope.float().numpy(), cos, sin,

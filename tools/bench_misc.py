@@ -40,10 +40,9 @@ def dec(ctx):
 
 
 for tgt in (256, 512, 1024, 2048):
-    os.environ['MI355_PAGED_TARGET_WGS'] = str(tgt)
-    us = timeit(lambda: dec(ragged))
+    with ops.debug_knob('MI355_PAGED_TARGET_WGS', tgt):
+        us = timeit(lambda: dec(ragged))
     print(f"ragged U[S/2,S] decode target_wgs={tgt}: {us:.1f} us -> {nbytes / us / 1e3:.0f} GB/s", flush=True)
-os.environ.pop('MI355_PAGED_TARGET_WGS')
 
 for vocab in (1000, 32000, 128256):
     logits = torch.randn((B, vocab), generator=g, device=dev)

@@ -23,10 +23,7 @@ ctx = torch.full((B,), S, dtype=torch.int32, device=dev)
 nbytes = B * S * (R + P) * 2 + B * H * (R + P) * 2 + B * H * R * 4
 flops = 2.0 * B * H * S * (R + P + R)
 for tgt in [int(x) for x in os.environ.get('MLA_TARGETS', '0,1024,2048,0').split(',')]:
-    if tgt:
-        os.environ['MI355_MLA_TARGET_WGS'] = str(tgt)
-    else:
-        os.environ.pop('MI355_MLA_TARGET_WGS', None)
+    ops._lib.load().mi355_debug_set_knob(b'MI355_MLA_TARGET_WGS', tgt)      # 0 = the library's own plan
     n = 60
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
     for i in range(n + 5):

@@ -19,10 +19,7 @@ cu = torch.arange(0, T + 1, L, dtype=torch.int32, device=dev)
 flops = 4.0 * nseq * Hq * D * (L * (L + 1) / 2)          # QK^T + PV over the causal triangle
 
 for name, env in (('mfma', None), ('valu', '1'))[:1 if os.environ.get('BENCH_MFMA_ONLY') else 2]:
-    if env:
-        os.environ['MI355_PREFILL_VALU'] = env
-    else:
-        os.environ.pop('MI355_PREFILL_VALU', None)
+    ops._lib.load().mi355_debug_set_knob(b'MI355_PREFILL_VALU', int(env or 0))
     n = 20 if name == 'mfma' else 5
     for _ in range(3):
         ops.prefill_causal(q, k, v, cu, L)

@@ -20,11 +20,11 @@ k = torch.randn(T, Hkv, D, device=dev, dtype=dtype)
 v = torch.randn(T, Hkv, D, device=dev, dtype=dtype)
 cu = torch.arange(0, T + 1, L, dtype=torch.int32, device=dev)
 flops = 4.0 * nseq * Hq * D * L * (L + 1) / 2
-os.environ['MI355_PREFILL_VALU'] = '1'
+ops._lib.load().mi355_debug_set_knob(b'MI355_PREFILL_VALU', 1)
 outs = {}
 for name, tiled, env in (('one query row per lane', '1', '1'), ('row groups of 8', '0', '1'), ('one row per workgroup', '0', '0')):
-    os.environ['MI355_PREFILL_F32_TILED'] = tiled
-    os.environ['MI355_PREFILL_ROW_GROUPS'] = env
+    ops._lib.load().mi355_debug_set_knob(b'MI355_PREFILL_F32_TILED', int(tiled))
+    ops._lib.load().mi355_debug_set_knob(b'MI355_PREFILL_ROW_GROUPS', int(env))
     for _ in range(2):
         outs[name] = ops.prefill_causal(q, k, v, cu, L)
     n = 5

@@ -2,7 +2,7 @@
 stream while the timed launches (each between two HIP events, KV pools rotating) are queued, so
 an event pair sees the device-side cost of a launch and not the host's call overhead.
 Usage: [MI355_PAGED_LIB=path] python tools/tune_c2.py [metric|c2] [NAME=VALUE[,NAME=VALUE] ...]
-Each argument after the config is one variant: environment settings applied for its launches."""
+Each argument after the config is one variant: launch-plan knobs (mi355_debug_set_knob) set for its launches."""
 import os
 import sys
 
@@ -22,11 +22,9 @@ out = torch.empty((B, H, D), dtype=torch.bfloat16, device=dev)
 nb = algorithmic_bytes(B, S, H, H, D, BS, 2)
 n = 100
 for var in variants:
-    saved = {}
-    for kv in filter(None, var.split(',')):
-        k, v = kv.split('=')
-        saved[k] = os.environ.get(k)
-        os.environ[k] = v
+    knobs = [kv.split('=') for kv in filter(None, var.split(','))]
+    for k, v in knobs:
+        ops._lib.check(ops._lib.load().mi355_debug_set_knob(k.encode(), int(v)), 'mi355_debug_set_knob')
     for i in range(10):
         kc, vc, bt = inp['pools'][i % len(inp['pools'])]
         ops.paged_decode(inp['q'], kc, vc, bt, inp['ctx'], S, out=out)
@@ -55,8 +53,5 @@ for var in variants:
     print(f"{name} [{var or 'default'}]: events avg {avg * 1e3:.1f} us  p50 {ms[n // 2] * 1e3:.1f}  min {ms[0] * 1e3:.1f}"
           f"  p90 {ms[n * 9 // 10] * 1e3:.1f} -> {nb / avg / 1e6 / 80:.1f}% of 8 TB/s;  back-to-back {b2b * 1e3:.1f} us "
           f"({nb / b2b / 1e6 / 80:.1f}%)", flush=True)
-    for k, v in saved.items():
-        if v is None:
-            os.environ.pop(k, None)
-        else:
-            os.environ[k] = v
+    for k, _ in knobs:
+        ops._lib.load().mi355_debug_set_knob(k.encode(), -2 ** 31)

@@ -18,7 +18,7 @@ B, S, H, D, BS = cfg['B'], cfg['S'], cfg['H'], cfg['D'], cfg['BS']
 out = torch.empty((B, H, D), dtype=torch.bfloat16, device=dev)
 nb = algorithmic_bytes(B, S, H, H, D, BS, 2)
 for tgt in targets:
-    os.environ['MI355_PAGED_TARGET_WGS'] = str(tgt)
+    ops._lib.load().mi355_debug_set_knob(b'MI355_PAGED_TARGET_WGS', tgt)
     n = 60
     ea = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
     eb = [torch.cuda.Event(enable_timing=True) for _ in range(n)]

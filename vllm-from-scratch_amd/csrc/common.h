@@ -20,11 +20,24 @@ constexpr int kWave = 64;
 // Records `code` and a printf-style message for mi355_last_error(); returns code.
 int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 
-// Integer tuning knob from the environment (unset or empty: the default).
-inline int env_int(const char* name, int dflt) {
-  const char* s = getenv(name);
-  return (s && *s) ? atoi(s) : dflt;
-}
+// Integer tuning knobs (launch-plan choices kept switchable for A/B measurements).  A knob's
+// value is its default, overridden by the environment variable of the same name -- read ONCE
+// per process, at the first use of any knob -- and after that only by mi355_debug_set_knob.
+// Reading a knob on the launch path is one relaxed atomic load.
+enum Knob {
+  kKnobDecodeGqaMfma,     // MI355_DECODE_GQA_MFMA     1: grouped-query decode on the matrix cores
+  kKnobPagedTargetWgs,    // MI355_PAGED_TARGET_WGS    workgroups a decode launch aims for
+  kKnobPagedHpw,          // MI355_PAGED_HPW           0: planned; else kv heads per decode workgroup
+  kKnobPagedPrefillMinQ,  // MI355_PAGED_PREFILL_MIN_Q chunk length from which the flash kernel serves paged chunks
+  kKnobPrefillValu,       // MI355_PREFILL_VALU        1: packed prompts stay off the matrix cores
+  kKnobPrefillF32Tiled,   // MI355_PREFILL_F32_TILED   1: fp32 prompts on the one-row-per-lane kernel
+  kKnobPrefillRowGroups,  // MI355_PREFILL_ROW_GROUPS  1: VALU prompts in groups of eight query rows
+  kKnobPrefillWaves,      // MI355_PREFILL_WAVES       0: planned; 4 or 8 waves per prompt workgroup
+  kKnobMlaManyHeads,      // MI355_MLA_MANY_HEADS      1: 64 heads per MLA workgroup above 16 heads
+  kKnobMlaTargetWgs,      // MI355_MLA_TARGET_WGS      0: planned; else workgroups an MLA launch aims for
+  kKnobCount
+};
+int knob(Knob k);
 // Returns 0 or records + returns the pending hipError_t of the last launch.
 int check_launch(const char* what);
 

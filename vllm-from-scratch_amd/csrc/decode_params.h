@@ -35,6 +35,7 @@ struct DecodeParams {
   const int32_t* seg_len;
   const int32_t* seg_pos0;
   int n_qt, tq, hgp_shift;
+  int max_q;   // host-side bound on seg_len the grid was sized for; device values are clamped to it
 };
 
 struct DecodePlan {

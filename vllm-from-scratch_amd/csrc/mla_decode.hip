@@ -782,7 +782,7 @@ int mla_plan(int rows, int H, int R, int P, int max_context, int dtype, MlaPlan*
   if (P <= 0 || P > 64 || P % 8) return fail(MI355_EUNSUPPORTED, "mla_decode: rope dim %d (multiple of 8, <= 64)", P);
   if (max_context < 0) return fail(MI355_EINVAL, "mla_decode: max_context %d", max_context);
   MlaPlan pl;
-  pl.many = R >= 128 && H > kHeadTile && env_int("MI355_MLA_MANY_HEADS", 1) != 0;   // 64 heads per workgroup
+  pl.many = R >= 128 && H > kHeadTile && knob(kKnobMlaManyHeads) != 0;   // 64 heads per workgroup
   pl.n_ht = pl.many ? (H + 4 * kHeadTile - 1) / (4 * kHeadTile) : (H + kHeadTile - 1) / kHeadTile;
   const int ctx = max_context > 0 ? max_context : 1;
   const int64_t base = (int64_t)rows * pl.n_ht;
@@ -790,7 +790,7 @@ int mla_plan(int rows, int H, int R, int P, int max_context, int dtype, MlaPlan*
   // before tokens are split -- with two tiles of prefetch per workgroup, few long workgroups
   // beat many short ones (measured at 256 rows x 4096 tokens: 187 us unsplit, 193 us with 2
   // splits, 212 us with 4).
-  const int target = env_int("MI355_MLA_TARGET_WGS", R >= 128 ? 256 : 2048);
+  const int target = knob(kKnobMlaTargetWgs) > 0 ? knob(kKnobMlaTargetWgs) : (R >= 128 ? 256 : 2048);
   int64_t want = ceil_div64(target, base);
   const int64_t most = ctx / 128 > 0 ? ctx / 128 : 1;           // at least 4 steps per workgroup
   if (want > most) want = most;

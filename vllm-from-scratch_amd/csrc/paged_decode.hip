@@ -78,8 +78,8 @@ __global__ void __launch_bounds__(kMaxThreads) paged_decode_kernel(const DecodeP
       len = p.cu[seq + 1] - lin_start;
       row0 = lin_start + first;
     } else {
-      len = p.seg_len[seq];
-      pos0 = max(p.seg_pos0[seq], 0);
+      len = min(p.seg_len[seq], p.max_q);             // device values, clamped to the host-side bounds
+      pos0 = min(max(p.seg_pos0[seq], 0), p.max_ctx);
       row0 = p.seg_q0[seq] + first;
       bt_row = seq;
     }
@@ -390,8 +390,9 @@ constexpr int kU = MI355_DECODE_U;  // 16-byte loads of K (and of V) per lane pe
 // memory counter with the prefetch loads and would serialise them).
 constexpr int steps_for_group(int G) { return G >= 8 ? (kU > 2 ? 2 : kU) : kU; }
 
-// Launch geometry for a problem shape.  Deterministic in its arguments (plus the
-// MI355_PAGED_TARGET_WGS tuning variable), so the workspace query and the launch agree.
+// Launch geometry for a problem shape.  Deterministic in its arguments (plus the launch-plan
+// knobs, which only mi355_debug_set_knob changes after start-up), so the workspace query and the
+// launch agree.
 int make_plan(int B, int Hq, int Hkv, int D, int block_size, int max_context, int dtype,
               DecodePlan* plan, bool causal = false) {
   if (B <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv) return fail(MI355_EINVAL, "bad B/Hq/Hkv (%d,%d,%d)", B, Hq, Hkv);
@@ -405,7 +406,7 @@ int make_plan(int B, int Hq, int Hkv, int D, int block_size, int max_context, in
   const int gq = Hq / Hkv;
   // Grouped-query shapes (>= 4 query heads per kv head, 16-bit, head_dim 64 / 128) go to the
   // matrix-core kernel; MI355_DECODE_GQA_MFMA=0 keeps them on the VALU kernel (A/B measurements).
-  pl.mfma = !causal && decode_gqa_supported(dtype, D, gq) && env_int("MI355_DECODE_GQA_MFMA", 1) != 0;
+  pl.mfma = !causal && decode_gqa_supported(dtype, D, gq) && knob(kKnobDecodeGqaMfma) != 0;
   pl.nw = pl.mfma ? kGqaWaves : 8;
   pl.G = pl.mfma ? kGqaHeads : gq >= 8 ? 8 : gq > 2 ? 4 : gq;  // query heads per wave
   pl.qchunks = (gq + pl.G - 1) / pl.G;
@@ -413,7 +414,7 @@ int make_plan(int B, int Hq, int Hkv, int D, int block_size, int max_context, in
   const int ts = pl.mfma ? kGqaTokens : (kWave / lpt) * steps_for_group(pl.G);  // tokens per wave per pipeline step
   const int ctx = max_context > 0 ? max_context : 1;
   // one 8-wave workgroup per CU, or two 4-wave ones, before tokens are split
-  const int target = env_int("MI355_PAGED_TARGET_WGS", 256);
+  const int target = knob(kKnobPagedTargetWgs);
   // Heads per workgroup.  Eight kv heads per workgroup fetch the eight head tiles of a block
   // (contiguous in the [block][head][row][d] layout) together.  When that leaves CUs idle,
   // fewer heads per workgroup with the freed waves taking token sub-ranges of the same head
@@ -421,7 +422,7 @@ int make_plan(int B, int Hq, int Hkv, int D, int block_size, int max_context, in
   // workgroup, token splits across workgroups need the merge kernel and a workspace trip.
   pl.hpw = pl.nw;
   while (pl.hpw > 1 && Hkv % pl.hpw) pl.hpw /= 2;
-  const int forced_hpw = env_int("MI355_PAGED_HPW", 0);
+  const int forced_hpw = knob(kKnobPagedHpw);
   if (forced_hpw > 0 && forced_hpw <= pl.hpw && pl.hpw % forced_hpw == 0) {
     pl.hpw = forced_hpw;
   } else if (!causal) {
@@ -605,6 +606,7 @@ int paged_prefill_rows(void* out, const void* q, int64_t q_stride_tok, const voi
   p.seg_len = seg_len;
   p.seg_pos0 = seg_pos0;
   p.n_qt = p.tq = p.hgp_shift = 0;
+  p.max_q = max_q_len;
   p.row_tiles = (max_q_len + kRowGroup - 1) / kRowGroup;
   const int64_t groups = (int64_t)nseg * p.row_tiles;
   if (groups * p.hgroups * p.qchunks >= (1LL << 31)) return fail(MI355_EINVAL, "paged_prefill: grid too large");
@@ -695,7 +697,7 @@ int paged_decode_impl(const char* what, void* out, const void* q, int64_t q_stri
   p.lds_bt_bytes = (int)pl.lds_bt_bytes;
   p.scale_log2e = scale * 1.4426950408889634f;
   p.seg_q0 = p.seg_len = p.seg_pos0 = nullptr;
-  p.n_qt = p.tq = p.hgp_shift = 0;
+  p.n_qt = p.tq = p.hgp_shift = p.max_q = 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (pl.mfma) return launch_gqa(p, pl, D, dtype, s);
   switch (dtype) {
@@ -814,7 +816,7 @@ extern "C" int mi355_paged_prefill(void* out, const void* q, int64_t q_stride_to
   // among 128 or 256 query rows through LDS.  Short chunks (a few tokens per sequence) keep the
   // decode-shaped kernel below, whose tiles are 16 query columns wide.
   // MI355_PAGED_PREFILL_MIN_Q moves the switch (A/B measurements).
-  if (prefill_mfma_supported(dtype, D) && scale > 0.f && max_q_len >= env_int("MI355_PAGED_PREFILL_MIN_Q", 48) &&
+  if (prefill_mfma_supported(dtype, D) && scale > 0.f && max_q_len >= knob(kKnobPagedPrefillMinQ) &&
       kv_stride_tok * 2 * (int64_t)block_size < (1LL << 32))
     return prefill_mfma_paged_launch(out, q, q_stride_tok, k_cache, v_cache, block_tables, seg_q_start, seg_len,
                                      seg_pos0, nseg, max_q_len, Hq, Hkv, D, block_size, max_blocks, num_blocks,
@@ -889,6 +891,7 @@ extern "C" int mi355_paged_prefill(void* out, const void* q, int64_t q_stride_to
   p.n_qt = n_qt;
   p.tq = tq;
   p.hgp_shift = hgp_shift;
+  p.max_q = max_q_len;
   return append_gqa_launch(p, pl, D, dtype, static_cast<hipStream_t>(stream));
 }
 
@@ -913,12 +916,12 @@ extern "C" int mi355_prefill_causal(void* out, const void* q, const void* k, con
   // the row maximum before scaling, which needs a positive scale, and addresses a tile's rows
   // with 32-bit byte offsets, which bounds the token stride.
   if (prefill_mfma_supported(dtype, D) && scale > 0.f && kv_stride_tok < (1LL << 24) &&
-      !env_int("MI355_PREFILL_VALU", 0))
+      !knob(kKnobPrefillValu))
     return prefill_mfma_launch(out, q, k, v, q_stride_tok, kv_stride_tok, cu_seqlens, nseq, total_tokens,
                                max_seqlen, Hq, Hkv, D, scale, dtype, static_cast<hipStream_t>(stream));
   // fp32 at head_dim 32 / 64 / 128: one query row per lane (prefill_f32.hip).
   // MI355_PREFILL_F32_TILED=0 keeps the decode-shaped kernel below (A/B measurements).
-  if (prefill_f32_supported(dtype, D) && env_int("MI355_PREFILL_F32_TILED", 1))
+  if (prefill_f32_supported(dtype, D) && knob(kKnobPrefillF32Tiled))
     return prefill_f32_launch(out, q, k, v, q_stride_tok, kv_stride_tok, cu_seqlens, nseq, max_seqlen, Hq, Hkv, D,
                               scale, static_cast<hipStream_t>(stream));
   DecodeParams p;
@@ -954,13 +957,15 @@ extern "C" int mi355_prefill_causal(void* out, const void* q, const void* k, con
   p.lds_bt_bytes = (int)pl.lds_bt_bytes;
   p.scale_log2e = scale * 1.4426950408889634f;
   p.row_tiles = 0;
+  p.seg_q0 = p.seg_len = p.seg_pos0 = nullptr;
+  p.n_qt = p.tq = p.hgp_shift = p.max_q = 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   // Row groups: one workgroup per (sequence, tile of kRowGroup query rows, kv-head group, query head of
   // the kv group).  MI355_PREFILL_ROW_GROUPS=0 keeps one query row per workgroup (A/B measurements).
   const size_t rows_lds = 16 + (pl.sub > 1 ? (size_t)pl.nw * kRowGroup * (D + 2) * sizeof(float) : 0);
   const int64_t row_tiles = ((int64_t)max_seqlen + kRowGroup - 1) / kRowGroup;
   const int64_t rows_grid = (int64_t)nseq * row_tiles * pl.hgroups * p.gq;
-  if (env_int("MI355_PREFILL_ROW_GROUPS", 1) && rows_lds <= kRowsMaxLds && rows_grid < (1LL << 31)) {
+  if (knob(kKnobPrefillRowGroups) && rows_lds <= kRowsMaxLds && rows_grid < (1LL << 31)) {
     p.row_tiles = (int)row_tiles;
     p.B = (int)(nseq * row_tiles);
     p.qchunks = p.gq;

@@ -100,9 +100,10 @@ __global__ void __launch_bounds__(kGqaWaves* kWave, 2) paged_decode_gqa_kernel(c
   bool col_ok;
   if constexpr (APPEND) {
     const int seg = b / p.n_qt, qt = b - seg * p.n_qt;
-    const int slen = p.seg_len[seg], tok0 = qt * p.tq;
+    // descriptors come from device memory: clamped to the host-side bounds the launch was sized for
+    const int slen = min(p.seg_len[seg], p.max_q), tok0 = qt * p.tq;
     if (tok0 >= slen) return;
-    const int ntok = min(p.tq, slen - tok0), pos0 = p.seg_pos0[seg];
+    const int ntok = min(p.tq, slen - tok0), pos0 = min(max(p.seg_pos0[seg], 0), p.max_ctx);
     const int ctok = c >> p.hgp_shift, chd = c & ((1 << p.hgp_shift) - 1);
     ctx = max(0, min(pos0 + tok0 + ntok, p.max_ctx));          // context of the tile's last query token
     col_limit = min(pos0 + tok0 + ctok + 1, ctx);               // causal: a query sees positions <= its own

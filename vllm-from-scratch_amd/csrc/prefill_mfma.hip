@@ -51,6 +51,7 @@ struct PrefillParams {
   const int32_t* seg_pos0;
   int64_t s_blk, s_head, s_tok;        // cache strides in elements
   int max_blocks, block_size, bs_shift, num_blocks;
+  int max_ctx;                         // paged mode: no key at or past this position is read (<= max_blocks * block_size)
   int64_t q_stride_tok, kv_stride_tok;
   int nseq, n_qt_max, max_seqlen, Hq, Hkv, total_tokens;
   float scale_log2e;
@@ -143,8 +144,10 @@ __global__ void __launch_bounds__(kWaves * kWave, 2) MI355_NO_PACKED_F32 prefill
   // nq query rows starting at row q_row0 of q / out; query i sits at position pos0 + i and sees
   // keys 0 .. pos0 + i of the len = pos0 + nq keys
   const int q_row0 = PAGED ? p.seg_q0[seq] : p.cu[seq];
-  const int nq = PAGED ? p.seg_len[seq] : p.cu[seq + 1] - q_row0;
-  const int pos0 = PAGED ? p.seg_pos0[seq] : 0;
+  // paged mode: segment descriptors come from device memory; whatever they hold, no key at or past
+  // max_ctx (which the table covers) is read, and queries at or past it are neither read nor written
+  const int pos0 = PAGED ? min(max(p.seg_pos0[seq], 0), p.max_ctx) : 0;
+  const int nq = PAGED ? min(min(p.seg_len[seq], p.max_seqlen), p.max_ctx - pos0) : p.cu[seq + 1] - q_row0;
   const int seq_start = q_row0;                         // packed mode: K/V rows are the sequence's own
   const int len = pos0 + nq;
   const int q0 = qt * kQT;
@@ -413,7 +416,7 @@ int launch_w(PrefillParams p, hipStream_t s) {
 // max_context = the longest key range a query tile walks.
 template <class Tag, int D, bool PAGED>
 int launch(const PrefillParams& p, int max_context, hipStream_t s) {
-  const int force = env_int("MI355_PREFILL_WAVES", 0);
+  const int force = knob(kKnobPrefillWaves);
   const int64_t wgs8 = (int64_t)p.nseq * ((p.max_seqlen + 8 * kQW - 1) / (8 * kQW)) * p.Hq;
   const bool big = force ? force == 8 : (max_context >= 4096 && p.max_seqlen >= 8 * kQW && wgs8 >= 2 * 256);
   return big ? launch_w<Tag, D, 8, PAGED>(p, s) : launch_w<Tag, D, 4, PAGED>(p, s);
@@ -446,7 +449,7 @@ int prefill_mfma_launch(void* out, const void* q, const void* k, const void* v, 
   p.bt = nullptr;
   p.seg_q0 = p.seg_len = p.seg_pos0 = nullptr;
   p.s_blk = p.s_head = p.s_tok = 0;
-  p.max_blocks = p.block_size = p.num_blocks = 0;
+  p.max_blocks = p.block_size = p.num_blocks = p.max_ctx = 0;
   p.bs_shift = -1;
   if (dtype == MI355_BF16)
     return D == 64 ? launch<BF16, 64, false>(p, max_seqlen, stream) : launch<BF16, 128, false>(p, max_seqlen, stream);
@@ -477,6 +480,8 @@ int prefill_mfma_paged_launch(void* out, const void* q, int64_t q_stride_tok, co
   p.s_tok = s_tok;
   p.max_blocks = max_blocks;
   p.block_size = block_size;
+  p.max_ctx = (int)((int64_t)max_context < (int64_t)max_blocks * block_size ? (int64_t)max_context
+                                                                             : (int64_t)max_blocks * block_size);
   p.bs_shift = ilog2_exact(block_size);
   p.q_stride_tok = q_stride_tok;
   p.kv_stride_tok = s_tok;

@@ -24,6 +24,25 @@ _LAYOUT_DIMS = {'NHSD': (0, 1, 2), 'NSHD': (0, 2, 1)}
 
 _workspaces = {}
 
+_KNOB_RESET = -2 ** 31
+
+
+class debug_knob:
+    """`with ops.debug_knob('MI355_PAGED_HPW', 1): ...` -- one launch-plan knob of the library set
+    for the block (mi355_debug_set_knob), then back to the process's start-up value.  For A/B
+    measurements and the tests that compare two kernels on the same inputs."""
+
+    def __init__(self, name: str, value: int):
+        self.name, self.value = name.encode(), int(value)
+
+    def __enter__(self):
+        _lib.check(_lib.load().mi355_debug_set_knob(self.name, self.value), 'mi355_debug_set_knob')
+        return self
+
+    def __exit__(self, *exc):
+        _lib.load().mi355_debug_set_knob(self.name, _KNOB_RESET)
+        return False
+
 
 def dtype_code(t: torch.Tensor) -> int:
     try:
@@ -77,8 +96,9 @@ def _on(dev: torch.device):
     return torch.cuda.device(dev)
 
 
-def _workspace(dev: torch.device, nbytes: int) -> Tuple[Optional[torch.Tensor], int]:
-    """A per-device scratch tensor that only ever grows (torch owns the memory).
+def _workspace(dev: torch.device, nbytes: int, stream: int) -> Tuple[Optional[torch.Tensor], int]:
+    """A scratch tensor per (device, stream) that only ever grows (torch owns the memory): two
+    streams running split launches at the same time must not share partials.
 
     While a HIP graph is being captured the scratch comes from the capture's own memory pool
     instead: a captured launch keeps the raw pointer, and the shared tensor may be replaced by a
@@ -88,10 +108,11 @@ def _workspace(dev: torch.device, nbytes: int) -> Tuple[Optional[torch.Tensor], 
     if torch.cuda.is_current_stream_capturing():
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         return ws, ws.numel()
-    ws = _workspaces.get(dev)
+    key = (dev, stream)
+    ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
-        _workspaces[dev] = ws
+        _workspaces[key] = ws
     return ws, ws.numel()
 
 
@@ -160,16 +181,19 @@ def paged_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
     code = dtype_code(q)
     if scale is None:
         scale = 1.0 / math.sqrt(D)
+    # the library plans for the context a table row can hold; size the workspace for that same bound
+    max_context = min(int(max_context), block_tables.shape[1] * g['block_size'])
     with _on(dev):
+        stream = _stream(dev)
         need = lib.mi355_paged_decode_workspace_bytes(B, Hq, g['heads'], D, g['block_size'],
-                                                      int(max_context), code)
-        ws, ws_bytes = _workspace(dev, need)
+                                                      max_context, code)
+        ws, ws_bytes = _workspace(dev, need, stream)
         rc = lib.mi355_paged_decode(
             out.data_ptr(), q.data_ptr(), _stride(q, 0), k_cache.data_ptr(), v_cache.data_ptr(),
             block_tables.data_ptr(), context_lens.data_ptr(), B, Hq, g['heads'], D,
-            g['block_size'], block_tables.shape[1], g['num_blocks'], int(max_context),
+            g['block_size'], block_tables.shape[1], g['num_blocks'], max_context,
             g['s_block'], g['s_head'], g['s_tok'], float(scale), code,
-            ws.data_ptr() if ws is not None else None, ws_bytes, _stream(dev))
+            ws.data_ptr() if ws is not None else None, ws_bytes, stream)
     _lib.check(rc, 'mi355_paged_decode')
     return out
 
@@ -364,8 +388,9 @@ def mla_decode(q: torch.Tensor, c_kv: torch.Tensor, k_rope: torch.Tensor, cos: t
     out = torch.empty((rows, H, R), dtype=torch.float32, device=dev)
     code = dtype_code(q)
     with _on(dev):
+        stream = _stream(dev)
         need = lib.mi355_mla_decode_workspace_bytes(rows, H, R, P, int(max_context), code)
-        ws, ws_bytes = _workspace(dev, need)
+        ws, ws_bytes = _workspace(dev, need, stream)
         rc = lib.mi355_mla_decode(
             out.data_ptr(), q.data_ptr(), _stride(q, 0),
             c_kv.data_ptr(), _stride(c_kv, 0), _stride(c_kv, 1),
@@ -373,7 +398,7 @@ def mla_decode(q: torch.Tensor, c_kv: torch.Tensor, k_rope: torch.Tensor, cos: t
             cos.data_ptr(), sin.data_ptr(), cos.shape[0], context_lens.contiguous().data_ptr(),
             row_seq.contiguous().data_ptr() if row_seq is not None else None,
             rows, H, R, P, int(max_context), float(scale), code,
-            ws.data_ptr() if ws is not None else None, ws_bytes, _stream(dev))
+            ws.data_ptr() if ws is not None else None, ws_bytes, stream)
     _lib.check(rc, 'mi355_mla_decode')
     return out
 
@@ -506,14 +531,33 @@ def decode_step_inputs(packed: torch.Tensor, table_pool: torch.Tensor, block_siz
     return i64[0], i64[1], i64[2], ctx, tables
 
 
+# MI355_PAGED_PREFILL=0 (read once, at import) sends chunks row by row through paged_decode (A/B measurements)
+PAGED_PREFILL_ENABLED = __import__('os').environ.get('MI355_PAGED_PREFILL', '1') != '0'
+
+
 def paged_prefill_supported(dtype: torch.dtype, head_dim: int) -> bool:
     """Shapes mi355_paged_prefill serves: 16-bit dtypes at head_dim 64 / 128 on the matrix-core
     kernels, fp32 and the other head dims on the VALU kernel (eight query rows per wave).  Anything
-    else goes row by row through paged_decode.  MI355_PAGED_PREFILL=0 forces the row path (A/B
-    measurements)."""
-    import os
-    return (dtype in (torch.float32, torch.bfloat16, torch.float16) and head_dim in (16, 32, 64, 128, 256)
-            and os.environ.get('MI355_PAGED_PREFILL', '1') != '0')
+    else goes row by row through paged_decode."""
+    return (PAGED_PREFILL_ENABLED and dtype in (torch.float32, torch.bfloat16, torch.float16)
+            and head_dim in (16, 32, 64, 128, 256))
+
+
+PAGED_PREFILL_STAGED_BLOCKS = 8190     # block-table entries one workgroup of the LDS-staging kernels can hold
+PAGED_PREFILL_FLASH_MIN_Q = 48         # from this chunk length on, 16-bit head_dim 64 / 128 chunks take the flash kernel
+
+
+def paged_prefill_serves(dtype: torch.dtype, head_dim: int, block_size: int, n_q: int, context: int) -> bool:
+    """Can a segment of n_q new tokens whose last one sits at position context - 1 be part of a
+    paged_prefill launch?  The flash-attention kernel (16-bit, head_dim 64 / 128, taken when the
+    longest segment of the launch has >= 48 tokens) reads the block table from memory and has no
+    context limit; the other two kernels stage a sequence's whole table in LDS, which bounds the
+    context at PAGED_PREFILL_STAGED_BLOCKS blocks.  Segments beyond that go row by row through
+    paged_decode, which splits long contexts."""
+    if not paged_prefill_supported(dtype, head_dim):
+        return False
+    flash = dtype in (torch.bfloat16, torch.float16) and head_dim in (64, 128) and n_q >= PAGED_PREFILL_FLASH_MIN_Q
+    return flash or context <= PAGED_PREFILL_STAGED_BLOCKS * block_size
 
 
 def paged_prefill(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, block_tables: torch.Tensor,

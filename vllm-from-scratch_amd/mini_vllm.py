@@ -510,12 +510,13 @@ def build_attn_plan(positions: Sequence[int], seq_lens: Sequence[int], is_prefil
                     reference_compat: bool = False,
                     device_tables: Optional[DeviceBlockTables] = None,
                     table_rows: Optional[Sequence[int]] = None,
-                    append_ok: bool = False) -> AttnPlan:
+                    append_ok=False) -> AttnPlan:
     """block_tables: per-request lists of block ids (host), or None for the reference's
     semantics.  When device_tables / table_rows are given (one row id per request) the paged
     rows' tables are gathered on the device instead of being rebuilt from the host lists.
     append_ok: the paged-prefill kernel covers this model, so prompt chunks that do not start
-    at position 0 become append segments instead of one paged-decode row per token."""
+    at position 0 become append segments instead of one paged-decode row per token; a callable
+    (n_q, context) -> bool decides per segment (contexts beyond what that kernel stages)."""
     causal_tok: List[int] = []
     cu = [0]
     max_len = 0
@@ -541,7 +542,7 @@ def build_attn_plan(positions: Sequence[int], seq_lens: Sequence[int], is_prefil
             paged_tok.append(tok)
             paged_ctx.append(1)
             paged_tab.append((0,))
-        elif prefill and append_ok and n_q > 1:
+        elif prefill and n_q > 1 and (append_ok(n_q, start + n_q) if callable(append_ok) else append_ok):
             app_meta[0].append(tok)
             app_meta[1].append(n_q)
             app_meta[2].append(start)
@@ -862,6 +863,9 @@ class MiniTransformer(nn.Module):
             positions_host = positions.tolist()
         head_dim = self.k_cache.shape[-1]
         append_ok = self.k_cache.is_cuda and ops.paged_prefill_supported(self.k_cache.dtype, head_dim)
+        if append_ok:
+            dtype, bs = self.k_cache.dtype, self.block_size
+            append_ok = lambda n_q, context: ops.paged_prefill_serves(dtype, head_dim, bs, n_q, context)
         plan = build_attn_plan(positions_host, seq_lens, is_prefill, block_tables,
                                _compute_device(self.k_cache), reference_compat, device_tables, table_rows,
                                append_ok=append_ok)
