@@ -100,10 +100,15 @@ argmax_kernel(int32_t* out, const typename Tag::elem_t* logits, int vocab, int64
       best_i = idx;
     }
   };
-  // 16-byte pieces, four independent loads in flight per thread; pieces are visited in
-  // increasing index order so "first occurrence" stays well defined per thread.
+  // 16-byte pieces, kFly independent loads in flight per thread: a row of up to 32768 fp32 logits
+  // (1024 threads x 8 pieces x 4 values) is requested in one go, so the row costs one trip to
+  // memory instead of one per group of loads.  The index is clamped rather than branched around
+  // (loads under a branch wait for their data one by one); pieces are visited in increasing index
+  // order so "first occurrence" stays well defined per thread.
+  // (512 threads x 16 loads and 256 x 32 measured 12 % and 2x slower: the per-element compares of
+  // a row then run on fewer waves)
   const int nvec = vec_ok ? vocab / EPL : 0;
-  constexpr int kFly = 4;
+  constexpr int kFly = 8;
   for (int c0 = tid; c0 < nvec; c0 += nt * kFly) {
     u32x4 raw[kFly];
 #pragma unroll
@@ -126,29 +131,31 @@ argmax_kernel(int32_t* out, const typename Tag::elem_t* logits, int vocab, int64
 
   float cv = nan_i != 0x7fffffff ? __builtin_nanf("") : best;
   int ci = nan_i != 0x7fffffff ? nan_i : best_i;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
+  auto fold = [&](int off) {
     const float ov = __shfl_xor(cv, off);
     const int oi = __shfl_xor(ci, off);
     if (cand_better(ov, oi, cv, ci)) {
       cv = ov;
       ci = oi;
     }
-  }
+  };
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) fold(off);
   const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
-  if (lane == 0) {
-    s_v[wave] = cv;
-    s_i[wave] = ci;
+  if (nw > 1) {
+    if (lane == 0) {
+      s_v[wave] = cv;
+      s_i[wave] = ci;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    // the waves' candidates meet in the first lanes of wave 0 (one LDS read each, four folds)
+    cv = lane < nw ? s_v[lane] : -__builtin_inff();
+    ci = lane < nw ? s_i[lane] : 0x7fffffff;
+#pragma unroll
+    for (int off = kMaxWaves / 2; off >= 1; off >>= 1) fold(off);
   }
-  __syncthreads();
-  if (tid == 0) {
-    for (int w = 1; w < nw; ++w)
-      if (cand_better(s_v[w], s_i[w], cv, ci)) {
-        cv = s_v[w];
-        ci = s_i[w];
-      }
-    out[blockIdx.x] = ci == 0x7fffffff ? 0 : ci;
-  }
+  if (tid == 0) out[blockIdx.x] = ci == 0x7fffffff ? 0 : ci;
 }
 
 // ------------------------------------------------------------------ philox
@@ -236,8 +243,12 @@ __device__ __forceinline__ float exp_nonpos(float d) {
 
 // VPT > 0: the row's probabilities live in registers (VPT per thread).
 // VPT == 0: they are recomputed from the logits on every pass (any vocab size).
-template <class Tag, int VPT, int NT>
+// VEC: the row is read in 16-byte pieces (row base and stride 16-byte aligned, vocab a multiple of
+// the piece): a thread owns the elements of pieces tid, tid + nt, ... instead of single elements.
+template <class Tag, int VPT, int NT, bool VEC>
 __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
+  constexpr int EPL = Tag::kEPL;
+  static_assert(!VEC || VPT % EPL == 0, "register rows hold whole pieces");
   __shared__ Exchange xch;
   __shared__ float s_scan[kMaxWaves];
   __shared__ int s_pick;
@@ -272,24 +283,63 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
   // for the thread's elements tid, tid + nt, ... in that order, kStreamU loads in flight per thread
   // (the index is clamped instead of branching around the load, so that the loads of a group
   // issue back to back; a load under a branch waits for its data before the next one starts).
-  constexpr int kStreamU = 8;
+  constexpr int kStreamU = VEC ? 4 : 8;
   auto stream_row = [&](auto fn) {
-    for (int i0 = tid; i0 < vocab; i0 += nt * kStreamU) {
-      float x[kStreamU];
+    if constexpr (VEC) {
+      const int nvec = vocab / EPL;
+      for (int c0 = tid; c0 < nvec; c0 += nt * kStreamU) {
+        u32x4 raw[kStreamU];
 #pragma unroll
-      for (int u = 0; u < kStreamU; ++u) x[u] = Tag::to_float(row[min(i0 + u * nt, vocab - 1)]);
+        for (int u = 0; u < kStreamU; ++u)
+          raw[u] = *reinterpret_cast<const u32x4*>(row + (int64_t)min(c0 + u * nt, nvec - 1) * EPL);
 #pragma unroll
-      for (int u = 0; u < kStreamU; ++u)
-        if (i0 + u * nt < vocab) fn(x[u], i0 + u * nt);
+        for (int u = 0; u < kStreamU; ++u)
+          if (c0 + u * nt < nvec) {
+            float f[EPL];
+            Tag::unpack(raw[u], f);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) fn(f[e], (c0 + u * nt) * EPL + e);
+          }
+      }
+    } else {
+      for (int i0 = tid; i0 < vocab; i0 += nt * kStreamU) {
+        float x[kStreamU];
+#pragma unroll
+        for (int u = 0; u < kStreamU; ++u) x[u] = Tag::to_float(row[min(i0 + u * nt, vocab - 1)]);
+#pragma unroll
+        for (int u = 0; u < kStreamU; ++u)
+          if (i0 + u * nt < vocab) fn(x[u], i0 + u * nt);
+      }
     }
+  };
+  // index of the thread's j-th register-resident element (ascending in j)
+  auto eidx = [&](int j) {
+    if constexpr (VEC) return ((j / EPL) * nt + tid) * EPL + (j % EPL);
+    else return j * nt + tid;
   };
   if constexpr (VPT > 0) {
     // all of the thread's loads first (clamped index, no branch), then the arithmetic
+    if constexpr (VEC) {
+      const int nvec = vocab / EPL;
+      u32x4 raw[VPT / EPL];
 #pragma unroll
-    for (int j = 0; j < VPT; ++j) pr[j] = Tag::to_float(row[min(j * nt + tid, vocab - 1)]);
+      for (int k = 0; k < VPT / EPL; ++k)
+        raw[k] = __builtin_nontemporal_load(
+            reinterpret_cast<const u32x4*>(row + (int64_t)min(k * nt + tid, nvec - 1) * EPL));
+#pragma unroll
+      for (int k = 0; k < VPT / EPL; ++k) {
+        float f[EPL];
+        Tag::unpack(raw[k], f);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) pr[k * EPL + e] = f[e];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < VPT; ++j) pr[j] = Tag::to_float(row[min(j * nt + tid, vocab - 1)]);
+    }
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
-      pr[j] = (j * nt + tid < vocab) ? div_shared(pr[j], temp, inv_t) : -__builtin_inff();
+      pr[j] = (eidx(j) < vocab) ? div_shared(pr[j], temp, inv_t) : -__builtin_inff();
       mx = fmaxf(mx, pr[j]);
     }
     mx = block_reduce(mx, fmaxop, xch, slot);
@@ -301,7 +351,7 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
     z = block_reduce(z, addf, xch, slot);
     const float inv_z = 1.0f / z;
 #pragma unroll
-    for (int j = 0; j < VPT; ++j) pr[j] = (j * nt + tid < vocab) ? div_shared(pr[j], z, inv_z) : -1.0f;   // -1 marks "no element"
+    for (int j = 0; j < VPT; ++j) pr[j] = (eidx(j) < vocab) ? div_shared(pr[j], z, inv_z) : -1.0f;   // -1 marks "no element"
   } else {
     stream_row([&](float x, int) { mx = fmaxf(mx, div_shared(x, temp, inv_t)); });
     mx = block_reduce(mx, fmaxop, xch, slot);
@@ -315,7 +365,7 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
     if constexpr (VPT > 0) {
 #pragma unroll
       for (int j = 0; j < VPT; ++j)
-        if (pr[j] >= 0.f) fn(pr[j], j * nt + tid);
+        if (pr[j] >= 0.f) fn(pr[j], eidx(j));
     } else {
       stream_row([&](float x, int i) { fn(prob_of(x), i); });
     }
@@ -505,7 +555,7 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
     __shared__ float s_walk_base;
     if (tid == picker) {
 #pragma unroll
-      for (int j = 0; j < VPT; ++j) s_walk[j] = (pr[j] >= 0.f && is_kept(pr[j], j * nt + tid)) ? pr[j] : 0.f;
+      for (int j = 0; j < VPT; ++j) s_walk[j] = (pr[j] >= 0.f && is_kept(pr[j], eidx(j))) ? pr[j] : 0.f;
       s_walk_base = excl;
     }
     __syncthreads();
@@ -521,7 +571,7 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
       const unsigned long long hit = __ballot(q > 0.f && run > target);
       const unsigned long long any = __ballot(q > 0.f);          // not empty: the picker's mass is > 0
       const int j = hit ? __ffsll((long long)hit) - 1 : 63 - __clzll((long long)any);
-      if (lane == 0) p.out[b] = j * nt + picker;
+      if (lane == 0) p.out[b] = VEC ? ((j / EPL) * nt + picker) * EPL + (j % EPL) : j * nt + picker;
     }
   } else {
     if (tid == picker) {
@@ -542,13 +592,22 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
 template <class Tag>
 int launch_sample(const SampleParams& p, int B, hipStream_t s) {
   const int v = p.vocab;
+  // 16-byte loads when every row starts on a 16-byte boundary and holds whole pieces
+  const bool vec = (((uintptr_t)p.logits | (uintptr_t)(p.row_stride * Tag::kBytes)) & 15) == 0 && v % Tag::kEPL == 0;
   // Register-resident rows up to 32768 entries (1024 threads x 32 values: 16 waves per CU hide
   // the latency of the dependent reduction chains better than 512 x 64); longer rows are
   // recomputed from the logits on every pass.
-  if (v <= 4 * 256) hipLaunchKernelGGL((sample_kernel<Tag, 4, 256>), dim3(B), dim3(256), 0, s, p);
-  else if (v <= 16 * 1024) hipLaunchKernelGGL((sample_kernel<Tag, 16, 1024>), dim3(B), dim3(1024), 0, s, p);
-  else if (v <= 32 * 1024) hipLaunchKernelGGL((sample_kernel<Tag, 32, 1024>), dim3(B), dim3(1024), 0, s, p);
-  else hipLaunchKernelGGL((sample_kernel<Tag, 0, 1024>), dim3(B), dim3(1024), 0, s, p);
+  if (v <= 4 * 256) hipLaunchKernelGGL((sample_kernel<Tag, 4, 256, false>), dim3(B), dim3(256), 0, s, p);
+  else if (v <= 16 * 1024) {
+    if (vec) hipLaunchKernelGGL((sample_kernel<Tag, 16, 1024, true>), dim3(B), dim3(1024), 0, s, p);
+    else hipLaunchKernelGGL((sample_kernel<Tag, 16, 1024, false>), dim3(B), dim3(1024), 0, s, p);
+  } else if (v <= 32 * 1024) {
+    if (vec) hipLaunchKernelGGL((sample_kernel<Tag, 32, 1024, true>), dim3(B), dim3(1024), 0, s, p);
+    else hipLaunchKernelGGL((sample_kernel<Tag, 32, 1024, false>), dim3(B), dim3(1024), 0, s, p);
+  } else {
+    if (vec) hipLaunchKernelGGL((sample_kernel<Tag, 0, 1024, true>), dim3(B), dim3(1024), 0, s, p);
+    else hipLaunchKernelGGL((sample_kernel<Tag, 0, 1024, false>), dim3(B), dim3(1024), 0, s, p);
+  }
   return check_launch("sample_kernel");
 }
 
