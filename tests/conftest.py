@@ -21,8 +21,35 @@ for p in (PKG, ROOT):
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 
+DP_JOB = None      # (Popen, output directory) of the two-rank engine job, when a GPU session started it
+
+
+def _start_dp_job():
+    """tests/dp_engine_job.py under torch.distributed.run, two ranks.  Started here, while this
+    process has made no GPU call yet (counting devices does not initialise the runtime): a process
+    that has initialised the GPU must not start other programs on this pool."""
+    import socket
+    import subprocess
+    import tempfile
+    out_dir = tempfile.mkdtemp(prefix='dp_engine_job_')
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    log = open(os.path.join(out_dir, 'job.log'), 'w')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(ROOT, 'tests', 'dp_engine_job.py'), out_dir]
+    return subprocess.Popen(cmd, stdout=log, stderr=subprocess.STDOUT, cwd=ROOT), out_dir
+
+
 def pytest_configure(config):
+    global DP_JOB
     config.addinivalue_line('markers', 'gpu: needs a HIP device (MI355X)')
+    markexpr = (config.getoption('markexpr', '') or '').strip()
+    if markexpr == 'gpu' and DP_JOB is None:
+        import torch
+        if torch.cuda.device_count() > 0:
+            DP_JOB = _start_dp_job()
 
 
 def load_npz(name):

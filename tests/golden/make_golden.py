@@ -303,6 +303,48 @@ def g7():
     save_npz('g7_sampler_big.npz', logits=big.numpy(), greedy_ids=np.array(greedy_big))
 
 
+def g7b():
+    """Nucleus rows at the benchmark's vocabulary (32000): what the reference's Sampler keeps.
+    Captured from inside Sampler.sample by observing its Tensor.sort (token order) and the
+    distribution it hands to torch.multinomial (renormalised, cut entries zero).  `margin` is
+    how far the exclusive cumulative mass at the cut is from top_p on either side, in units of
+    the row's largest fp32 cumulative-sum spacing (2^-24): a kept set is only well defined
+    against another implementation's rounding when that is comfortably above 1."""
+    g = torch.Generator().manual_seed(32000)
+    V = 32000
+    params = [(1.0, 0.9), (0.7, 0.5), (1.3, 0.95), (0.5, 0.99)]
+    logits = torch.randn(len(params), V, generator=g) * torch.tensor([[1.0], [2.0], [1.5], [3.0]])
+    arrays = dict(logits=logits.numpy(), temperature=np.array([t for t, _ in params], dtype=np.float32),
+                  top_p=np.array([p for _, p in params], dtype=np.float32))
+    real_sort, real_multinomial = torch.Tensor.sort, torch.multinomial
+    try:
+        for i, (row, (temp, top_p)) in enumerate(zip(logits, params)):
+            seen = {}
+
+            def spy_sort(*a, **kw):
+                out = real_sort(*a, **kw)
+                seen['ids'] = out[1].clone()
+                seen['sorted'] = out[0].clone()
+                return out
+
+            def fake_multinomial(probs, n):
+                seen['probs'] = probs.clone()
+                return torch.tensor([0])
+
+            torch.Tensor.sort, torch.multinomial = spy_sort, fake_multinomial
+            ref_mv.Sampler.sample(row[None, :], [ref_mv.Request('r', [1], 1, temperature=temp, top_p=top_p)])
+            kept = int((seen['probs'] > 0).sum())
+            excl = torch.cumsum(seen['sorted'], dim=-1) - seen['sorted']
+            margin = min(float(top_p - excl[kept - 1]), float(excl[kept] - top_p)) / 2.0 ** -24
+            arrays[f'kept_ids_sorted_{i}'] = seen['ids'][:kept].numpy().astype(np.int32)
+            arrays[f'kept_probs_sorted_{i}'] = seen['probs'][:kept].numpy()
+            arrays[f'margin_{i}'] = np.array(margin)
+            print(f'  g7b row {i}: T={temp} top_p={top_p}: kept {kept} of {V}, margin {margin:.1f} x 2^-24')
+    finally:
+        torch.Tensor.sort, torch.multinomial = real_sort, real_multinomial
+    save_npz('g7_sampler_vocab32000.npz', **arrays)
+
+
 # ---------------------------------------------------------------- G8
 def g8():
     torch.manual_seed(2024)
@@ -392,6 +434,9 @@ def g9():
 
 
 if __name__ == '__main__':
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9):
+    only = [a for a in sys.argv[2:]]           # e.g. `make_golden.py /root/reference g7b`: just those fixtures
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g7b, g8, g9):
+        if only and fn.__name__ not in only:
+            continue
         fn()
         print('wrote', fn.__name__)

@@ -104,3 +104,87 @@ def test_overlapped_gather_batched_single_process():
     g.flush()
     assert g.result(3).tolist() == [30, 31]
     g.drain()
+
+
+# ---------------------------------------------------------------- engine-level data parallelism
+# The real scheduler, allocator and engine loop on the CPU; only the two steps that need a GPU
+# (model forward, sampling) are replaced by a deterministic rule, so that the sharded run can be
+# compared with a single engine on the whole batch without a device.
+
+_ENGINE_CFG = dict(vocab_size=97, hidden_size=32, num_layers=1, num_heads=2, intermediate_size=64,
+                   num_kv_blocks=64, block_size=4, max_num_seqs=3, max_num_batched_tokens=16,
+                   enable_chunked_prefill=True, device='cpu',
+                   reference_compat=True)      # no device-side block tables: nothing here touches a GPU
+_PROMPTS = [[5, 6, 7], list(range(1, 30)), [9], [4, 4, 4, 4, 4, 4, 4, 4, 4], [11, 12], list(range(40, 61)),
+            [3, 1, 4, 1, 5, 9, 2, 6]]
+
+
+def _rule_engine(engine):
+    """Next token = a fixed function of a request's last fed token and its position (token 0 ends
+    a request early, as in the reference)."""
+    vocab = engine.model.lm_head.weight.shape[0]
+
+    def forward(token_ids, positions, slot_mapping, seq_lens, is_prefill, **kw):
+        last, at = [], 0
+        for n in seq_lens:
+            at += n
+            last.append(at - 1)
+        tok, pos = token_ids[last], positions[last]
+        nxt = (tok * 31 + pos * 7 + 3) % 13           # small range: token 0 (end of sequence) turns up
+        return torch.nn.functional.one_hot(nxt, vocab).float()
+
+    engine.model.forward = forward
+    engine.sampler.sample = lambda logits, requests: [int(t) for t in logits.argmax(dim=-1).tolist()]
+    return engine
+
+
+def _dp_engine_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import mini_vllm
+        torch.manual_seed(100 + rank)                     # different initial weights: rank 0's are broadcast
+        front = mini_vllm.DataParallelMiniVLLM(**_ENGINE_CFG)
+        w = front.engine.model.lm_head.weight.detach().clone()
+        _rule_engine(front.engine)
+        first = front.generate(_PROMPTS, max_new_tokens=6, temperature=0.0)
+        second = front.generate(_PROMPTS[:3], max_new_tokens=4, temperature=0.0)     # the front end is reusable
+        torch.save(dict(first=first, second=second, lm_head=w, local=front.engine._req_counter),
+                   os.path.join(out_dir, f'dp{rank}.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_engine_data_parallel_world2_equals_single_engine(tmp_path):
+    import mini_vllm
+    single = _rule_engine(mini_vllm.MiniVLLM(**_ENGINE_CFG))
+    want = {}
+    ids = [single.add_request(p, max_new_tokens=6, temperature=0.0) for p in _PROMPTS]
+    want = {rid: [] for rid in ids}
+    while single.scheduler.has_unfinished:
+        for rid, tok in single.step():
+            want[rid].append(tok)
+    assert any(len(v) < 6 for v in want.values()) and any(len(v) == 6 for v in want.values())   # early ends and full runs
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(_dp_engine_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = [torch.load(tmp_path / f'dp{r}.pt') for r in range(2)]
+    for r in range(2):
+        assert got[r]['first'] == want                                   # every rank holds every request's tokens
+        assert got[r]['second'] == {f'req-{7 + i}': want[f'req-{i}'][:4] for i in range(3)}
+    assert torch.equal(got[0]['lm_head'], got[1]['lm_head'])             # replicated weights
+    assert got[0]['local'] == 4 + 2 and got[1]['local'] == 3 + 1         # 7 -> 4 + 3 rows, then 3 -> 2 + 1
+
+
+def test_engine_data_parallel_without_a_group_is_the_single_engine():
+    import mini_vllm
+    front = mini_vllm.DataParallelMiniVLLM(**_ENGINE_CFG)
+    _rule_engine(front.engine)
+    single = _rule_engine(mini_vllm.MiniVLLM(**_ENGINE_CFG))
+    ids = [single.add_request(p, max_new_tokens=5, temperature=0.0) for p in _PROMPTS]
+    want = {rid: [] for rid in ids}
+    while single.scheduler.has_unfinished:
+        for rid, tok in single.step():
+            want[rid].append(tok)
+    assert front.generate(_PROMPTS, max_new_tokens=5, temperature=0.0) == want

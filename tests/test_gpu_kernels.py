@@ -801,6 +801,30 @@ def test_nucleus_kept_set_matches_reference(ops, device):
         assert int(ids[i]) in kept
 
 
+def test_nucleus_kept_set_matches_reference_at_vocab_32000(ops, device):
+    """Fixture rows generated by the reference's Sampler at the benchmark's vocabulary: the
+    kernel must keep exactly the reference's tokens and give them the reference's renormalised
+    probabilities.  A fifth row repeats row 0 with a top-k limit added; the reference has no top-k,
+    so that row is held to the oracle's restatement (top-k, then the nucleus cut) -- for top-k,
+    parity with the reference is unpinned by construction."""
+    z = load_npz('g7_sampler_vocab32000.npz')
+    n = len(z['temperature'])
+    logits = torch.from_numpy(np.concatenate([z['logits'], z['logits'][:1]])).to(device)
+    temp = torch.from_numpy(np.concatenate([z['temperature'], z['temperature'][:1]])).to(device)
+    top_p = torch.from_numpy(np.concatenate([z['top_p'], z['top_p'][:1]])).to(device)
+    top_k = torch.tensor([0] * n + [5000], dtype=torch.int32, device=device)
+    ids, probs = ops.sample_topk_topp(logits, temp, top_p, top_k, seed=3, return_probs=True)
+    probs, ids = probs.cpu().numpy(), ids.cpu().numpy()
+    for i in range(n):
+        want_ids = z[f'kept_ids_sorted_{i}']
+        assert np.array_equal(np.nonzero(probs[i])[0], np.sort(want_ids))          # exact set
+        np.testing.assert_allclose(probs[i][want_ids], z[f'kept_probs_sorted_{i}'], rtol=1e-4, atol=1e-9)
+        assert probs[i][ids[i]] > 0
+    want, kept = orc.nucleus_probs(z['logits'][0], float(z['temperature'][0]), float(z['top_p'][0]), top_k=5000)
+    assert kept.sum() == 5000 and np.array_equal(np.nonzero(probs[n])[0], np.nonzero(kept)[0])
+    np.testing.assert_allclose(probs[n], want, rtol=1e-4, atol=1e-9)
+
+
 @pytest.mark.parametrize('vocab', [50, 1000, 5000, 32000, 70000])
 def test_sampling_filters_match_oracle(ops, device, vocab):
     rng = np.random.default_rng(vocab)

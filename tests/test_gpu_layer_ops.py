@@ -196,6 +196,54 @@ def test_engine_lookahead_decode_equals_step_by_step(device, dtype):
     assert sorted(r.request_id for r in ahead.scheduler.finished) == sorted(r.request_id for r in eager.scheduler.finished)
 
 
+def test_engine_lookahead_eos_on_a_block_boundary_with_prefix_caching(device):
+    """A request that samples the end-of-sequence id has the next step already issued; that
+    step's row writes K/V one position further -- into a block taken early when the position
+    opens a new block -- and the request's blocks are freed right after.  With prefix caching on,
+    freed prompt blocks stay adoptable: the stray row must never land in one of them, and a freed
+    block handed to another request must end up holding that request's rows.  The case is searched
+    for, not hoped for: prompts share block-aligned prefixes, the pool is small enough that freed
+    blocks are reused at once, and the run must contain requests that end on the end-of-sequence
+    id with their next position on a block boundary.  Two passes over the same prompts: the second
+    adopts the blocks the first left cached, and both must give the eager engine's tokens."""
+    import mini_vllm as mv
+    bs = 8
+    rng = np.random.default_rng(5)
+    stems = [[int(t) for t in rng.integers(1, 12, size=n)] for n in (16, 24, 8)]
+    prompts = []
+    for i in range(30):
+        tail = [int(t) for t in rng.integers(1, 12, size=int(rng.integers(1, 9)))]
+        prompts.append(stems[i % 3] + tail)
+    max_new = [int(n) for n in rng.integers(6, 40, size=len(prompts))]
+
+    def run(**kw):
+        torch.manual_seed(7)
+        eng = mv.MiniVLLM(vocab_size=12, hidden_size=128, num_layers=2, num_heads=4, intermediate_size=256,
+                          num_kv_blocks=48, block_size=bs, max_num_seqs=6, max_num_batched_tokens=256,
+                          device='cuda', dtype=torch.float32, **kw)
+        passes = []
+        for _ in range(2):
+            ids = [eng.add_request(p, max_new_tokens=n, temperature=0.0) for p, n in zip(prompts, max_new)]
+            outs = {rid: [] for rid in ids}
+            while eng.scheduler.has_unfinished:
+                for rid, tok in eng.step():
+                    outs[rid].append(tok)
+            passes.append([outs[rid] for rid in ids])
+        return eng, passes
+
+    _, want = run(decode_graphs=False)
+    assert want[0] == want[1]                       # greedy: a request's tokens depend on its prompt only
+    boundary_ends = [i for i, toks in enumerate(want[0])
+                     if toks[-1] == 0 and len(toks) < max_new[i] and (len(prompts[i]) + len(toks)) % bs == 0]
+    assert len(boundary_ends) >= 2, "the case is meant to end requests with their next position opening a block"
+    eng, got = run(decode_graphs=True, decode_lookahead=True, enable_prefix_caching=True)
+    assert got == want
+    assert eng._launches > 20 and eng._inflight is None
+    assert eng.allocator.num_free == 48
+    cached = run(decode_graphs=False, enable_prefix_caching=True)[1]
+    assert cached == want
+
+
 def test_engine_more_requests_than_slots_equals_eager(device):
     """Continuous batching with a waiting queue: captured decode steps (and steps issued ahead) run
     while every sequence slot is taken, the general path takes over the moment a slot frees.  Every

@@ -86,6 +86,17 @@ def test_g7_nucleus():
         assert abs(float(probs.sum()) - 1.0) < 1e-5
 
 
+def test_g7_nucleus_at_vocab_32000():
+    """The kept set the reference's Sampler produces at the benchmark's vocabulary size."""
+    z = load_npz('g7_sampler_vocab32000.npz')
+    for i in range(len(z['temperature'])):
+        probs, kept = orc.nucleus_probs(z['logits'][i], float(z['temperature'][i]), float(z['top_p'][i]))
+        ids = z[f'kept_ids_sorted_{i}']
+        assert float(z[f'margin_{i}']) > 8          # the cut is not within rounding of top_p
+        assert np.array_equal(np.nonzero(kept)[0], np.sort(ids))                  # kept set exact
+        np.testing.assert_allclose(probs[ids], z[f'kept_probs_sorted_{i}'], rtol=1e-5, atol=1e-9)
+
+
 @pytest.mark.parametrize('case', npz_cases('g2_decode_cases.npz'), ids=lambda c: str(c[0]))
 def test_c_port_against_golden(case):
     from oracle import c_port

@@ -1254,3 +1254,112 @@ class MiniVLLM:
                 if rid in outputs:
                     outputs[rid].append(tok)
         return outputs
+
+
+# ---------------------------------------------------------------------------
+# data-parallel front end (no counterpart in the reference, which is single-device)
+# ---------------------------------------------------------------------------
+
+class DataParallelMiniVLLM:
+    """MiniVLLM.generate over the ranks of a torch.distributed group, one process per GPU.
+
+    Sequences never interact on this path, so the batch is cut by rows: rank r serves the
+    contiguous slice `dp.shard_bounds(len(prompts), world, r)` with an engine of its own (its own
+    BlockAllocator, Scheduler and KV buffers; weights replicated, broadcast from rank 0 when the
+    engine is built).  The only exchange is one all-gather per engine step of the ids that step
+    sampled (backend "nccl" = RCCL over xGMI; "gloo" for CPU rehearsals), so that every rank --
+    whichever one the front end talks to -- holds every request's tokens.  A rank's contribution
+    to a step is a fixed-size int32 vector: up to max_num_seqs (local request index, token id)
+    pairs, -1 padded, and a last entry saying whether the rank still has unfinished requests.
+    The collective of step i runs while step i + 1 computes (dp.OverlappedTokenGather); ranks do
+    not need each other's ids to go on decoding.  All ranks leave the loop on the same iteration:
+    the first one whose gathered vectors say that nobody has work left.
+
+    Under greedy sampling the result equals, token for token, what one engine returns for the whole
+    list of prompts: a request's tokens depend only on its own prompt and the weights.
+    """
+
+    def __init__(self, group=None, **engine_kwargs):
+        import torch.distributed as dist
+        from mi355_paged import dp
+        self._dp = dp
+        self.group = group
+        on = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if on else 0
+        self.world = dist.get_world_size(group) if on else 1
+        self.engine = MiniVLLM(**engine_kwargs)
+        self._req_counter = 0
+        backend = dist.get_backend(group) if on else None
+        # the collective moves device memory with RCCL and host memory with gloo
+        self._wire_device = self.engine.device if backend == 'nccl' else torch.device('cpu')
+        if self.world > 1:
+            self._replicate_weights(dist, backend)
+        self.cap = self.engine.scheduler.max_num_seqs
+        self._gather = dp.OverlappedTokenGather(2 * self.cap + 1, self._wire_device, group=group)
+        # one staging vector per buffer pair of the gather: a vector is rewritten only after the
+        # collective that read its previous contents has been waited for
+        self._host = [torch.zeros((2 * self.cap + 1,), dtype=torch.int32) for _ in range(self._gather.SLOTS)]
+        if self._wire_device.type == 'cuda':
+            self._host = [h.pin_memory() for h in self._host]
+
+    def _replicate_weights(self, dist, backend) -> None:
+        """Every rank takes rank 0's parameters and tables (the KV buffers are per-rank state)."""
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        for name, t in list(self.engine.model.named_parameters()) + list(self.engine.model.named_buffers()):
+            if name in ('k_cache', 'v_cache'):
+                continue
+            data = t.data
+            if backend == 'gloo' and data.is_cuda:
+                host = data.cpu()
+                dist.broadcast(host, src=src, group=self.group)
+                data.copy_(host)
+            else:
+                dist.broadcast(data, src=src, group=self.group)
+
+    def generate(self, prompts: List[List[int]], max_new_tokens: int = 20, temperature: float = 1.0,
+                 top_p: float = 1.0):
+        """{request_id: generated token ids} for ALL prompts, identical on every rank; request ids
+        count over the whole list ("req-0" is prompts[0]) as a single engine's would."""
+        lo, hi = self._dp.shard_bounds(len(prompts), self.world, self.rank)
+        bounds = [self._dp.shard_bounds(len(prompts), self.world, r) for r in range(self.world)]
+        base = self._req_counter
+        self._req_counter += len(prompts)
+        outputs = {f"req-{base + i}": [] for i in range(len(prompts))}
+        local_index = {}
+        for i in range(lo, hi):
+            rid = self.engine.add_request(prompts[i], max_new_tokens=max_new_tokens, temperature=temperature,
+                                          top_p=top_p)
+            local_index[rid] = i - lo
+        gather, cap, step = self._gather, self.cap, 0
+
+        def consume(s: int) -> bool:
+            """File step s's tokens under their requests; True when no rank has work left."""
+            vec = gather.result(s).view(self.world, 2 * cap + 1).cpu().tolist()
+            busy = False
+            for r, row in enumerate(vec):
+                for j in range(cap):
+                    idx, tok = row[2 * j], row[2 * j + 1]
+                    if idx < 0:
+                        break
+                    outputs[f"req-{base + bounds[r][0] + idx}"].append(tok)
+                busy = busy or row[2 * cap] != 0
+            return not busy
+
+        while True:
+            results = self.engine.step() if self.engine.scheduler.has_unfinished else []
+            if len(results) > cap:
+                raise RuntimeError(f"a step produced {len(results)} tokens for {cap} sequence slots")
+            host = self._host[step % len(self._host)]
+            host.fill_(-1)
+            for j, (rid, tok) in enumerate(results):
+                host[2 * j] = local_index[rid]
+                host[2 * j + 1] = tok
+            host[2 * cap] = 1 if self.engine.scheduler.has_unfinished else 0
+            gather.send_buffer(step).copy_(host, non_blocking=True)
+            gather.launch(step)
+            # step - 1's collective has had a whole engine step to complete
+            if step >= 1 and consume(step - 1):
+                break
+            step += 1
+        gather.drain()        # the last launch carried no tokens: nobody had work when it was issued
+        return outputs
