@@ -208,15 +208,17 @@ def test_engine_lookahead_eos_on_a_block_boundary_with_prefix_caching(device):
     adopts the blocks the first left cached, and both must give the eager engine's tokens."""
     import mini_vllm as mv
     bs = 8
-    rng = np.random.default_rng(5)
-    stems = [[int(t) for t in rng.integers(1, 12, size=n)] for n in (16, 24, 8)]
-    prompts = []
-    for i in range(30):
-        tail = [int(t) for t in rng.integers(1, 12, size=int(rng.integers(1, 9)))]
-        prompts.append(stems[i % 3] + tail)
-    max_new = [int(n) for n in rng.integers(6, 40, size=len(prompts))]
 
-    def run(**kw):
+    def workload(seed):
+        rng = np.random.default_rng(seed)
+        stems = [[int(t) for t in rng.integers(1, 12, size=n)] for n in (16, 24, 8)]
+        prompts = []
+        for i in range(48):
+            tail = [int(t) for t in rng.integers(1, 12, size=int(rng.integers(1, 9)))]
+            prompts.append(stems[i % 3] + tail)
+        return prompts, [int(n) for n in rng.integers(6, 40, size=len(prompts))]
+
+    def run(prompts, max_new, **kw):
         torch.manual_seed(7)
         eng = mv.MiniVLLM(vocab_size=12, hidden_size=128, num_layers=2, num_heads=4, intermediate_size=256,
                           num_kv_blocks=48, block_size=bs, max_num_seqs=6, max_num_batched_tokens=256,
@@ -231,16 +233,22 @@ def test_engine_lookahead_eos_on_a_block_boundary_with_prefix_caching(device):
             passes.append([outs[rid] for rid in ids])
         return eng, passes
 
-    _, want = run(decode_graphs=False)
-    assert want[0] == want[1]                       # greedy: a request's tokens depend on its prompt only
-    boundary_ends = [i for i, toks in enumerate(want[0])
-                     if toks[-1] == 0 and len(toks) < max_new[i] and (len(prompts[i]) + len(toks)) % bs == 0]
+    # the k-th output being the end-of-sequence id, the step issued ahead feeds it at position
+    # prompt_len + k - 1: that row's cache write opens a new block when the position is a multiple of bs
+    for seed in range(5, 15):
+        prompts, max_new = workload(seed)
+        _, want = run(prompts, max_new, decode_graphs=False)
+        boundary_ends = [i for i, toks in enumerate(want[0])
+                         if toks[-1] == 0 and len(toks) < max_new[i] and (len(prompts[i]) + len(toks) - 1) % bs == 0]
+        if len(boundary_ends) >= 2:
+            break
     assert len(boundary_ends) >= 2, "the case is meant to end requests with their next position opening a block"
-    eng, got = run(decode_graphs=True, decode_lookahead=True, enable_prefix_caching=True)
+    assert want[0] == want[1]                       # greedy: a request's tokens depend on its prompt only
+    eng, got = run(prompts, max_new, decode_graphs=True, decode_lookahead=True, enable_prefix_caching=True)
     assert got == want
     assert eng._launches > 20 and eng._inflight is None
     assert eng.allocator.num_free == 48
-    cached = run(decode_graphs=False, enable_prefix_caching=True)[1]
+    cached = run(prompts, max_new, decode_graphs=False, enable_prefix_caching=True)[1]
     assert cached == want
 
 
