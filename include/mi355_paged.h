@@ -285,6 +285,8 @@ int mi355_silu_mul(void* out, const void* gate, int64_t gate_stride, const void*
  * step; reading it on the device lets the next step be issued before the host has seen it).
  * prev_ids is int32 [prev_rows] and may be NULL when prev_rows is 0.
  * table_pool is [pool_rows, width] int32.
+ * block_tables may be NULL: the rows' tables are then not gathered (a step whose rows are the
+ * tokens of prompt chunks, which share their sequence's table, gathers per sequence instead).
  */
 int mi355_decode_step_inputs(int64_t* token_ids, int64_t* positions, int64_t* slots,
                              int32_t* context_lens, int32_t* block_tables, const int32_t* packed,

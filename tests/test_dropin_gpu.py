@@ -291,13 +291,12 @@ def test_engine_true_context_decode(mv, device):
     for p in meta['prompts']:
         eng.add_request(p, max_new_tokens=meta['max_new_tokens'], temperature=0.0)
     seen = []
-    forward = eng.model.forward
-    eng.model.forward = lambda *a, **k: seen.append(forward(*a, **k)) or seen[-1]
     outs = {}
     while eng.scheduler.has_unfinished:
         for rid, tok in eng.step():
             outs.setdefault(rid, []).append(tok)
-    np.testing.assert_allclose(seen[0].cpu().numpy(), ref_logits[0], atol=2e-4, rtol=1e-4)
+        seen.append(eng.last_logits.float().cpu())
+    np.testing.assert_allclose(seen[0].numpy(), ref_logits[0], atol=2e-4, rtol=1e-4)
     # dense check: feed prompt + generated tokens as ONE prompt to a fresh engine; its last-token
     # logits must pick the same next token the paged decode picked at each step
     for i, p in enumerate(meta['prompts']):
@@ -325,14 +324,11 @@ def test_engine_chunked_prefill_equals_unchunked(mv, device):
     logs = {}
     for name, eng in (('whole', whole), ('chunked', chunked)):
         eng.add_request(prompt, max_new_tokens=1, temperature=0.0)
-        f = eng.model.forward
-        cap = []
-        eng.model.forward = lambda *a, _f=f, _c=cap, **k: _c.append(_f(*a, **k)) or _c[-1]
         steps = 0
         while eng.scheduler.has_unfinished:
             eng.step()
             steps += 1
-        logs[name] = (cap[-1], steps)
+        logs[name] = (eng.last_logits.clone(), steps)
     assert logs['whole'][1] == 1 and logs['chunked'][1] == 3
     assert torch.allclose(logs['whole'][0], logs['chunked'][0], atol=1e-4)
 
@@ -413,9 +409,6 @@ def test_engine_prefix_caching_same_tokens_fewer_computed(mv, device):
     for caching in (False, True):
         torch.manual_seed(2)
         eng = mv.MiniVLLM(**kw, enable_prefix_caching=caching)
-        logits = []
-        forward = eng.model.forward_planned
-        eng.model.forward_planned = lambda *a, _f=forward, _l=logits, **k: _l.append(_f(*a, **k)) or _l[-1]
         outs = []
         for p in prompts:                                                  # one after another: later ones can hit
             rid = eng.add_request(p, max_new_tokens=6, temperature=0.0)
@@ -425,7 +418,7 @@ def test_engine_prefix_caching_same_tokens_fewer_computed(mv, device):
                 for r, tok in eng.step():
                     got.append(tok)
                 if first is None:
-                    first = logits[-1][0].float().cpu()
+                    first = eng.last_logits[0].float().cpu()
             outs.append((got, first))
         results[caching] = (outs, dict(eng.scheduler.prefix_stats), eng.allocator.num_free)
     plain, cached = results[False], results[True]
@@ -438,13 +431,14 @@ def test_engine_prefix_caching_same_tokens_fewer_computed(mv, device):
 
 
 def test_engine_bf16_chunked_prefill_uses_paged_prefill_kernel(mv, device, monkeypatch):
-    """bf16 engine, head_dim 64: later chunks of a chunked prompt go through mi355_paged_prefill
-    (one launch per layer and step, not one paged-decode row per token) and the first generated
-    token's logits stay close to the un-chunked bf16 run and to the fp32 run of the same weights
-    (tolerance: bf16 activations through 2 layers, logits of magnitude ~1)."""
+    """bf16 engine, head_dim 64: the chunks of a chunked prompt go through mi355_paged_prefill
+    (one launch per layer and step; the paged-decode launch beside it covers request slots, never
+    one row per prompt token) and the first generated token's logits stay close to the un-chunked
+    bf16 run and to the fp32 run of the same weights (tolerance: bf16 activations through 2 layers,
+    logits of magnitude ~1).  Engines without graphs, so that every step's launches are seen."""
     from mi355_paged import ops
     kw = dict(vocab_size=160, hidden_size=256, num_layers=2, num_heads=4, intermediate_size=256,
-              num_kv_blocks=64, block_size=16, max_num_seqs=4, device='cuda')
+              num_kv_blocks=64, block_size=16, max_num_seqs=4, device='cuda', decode_graphs=False)
     torch.manual_seed(6)
     ref32 = mv.MiniVLLM(**kw, max_num_batched_tokens=512, enable_chunked_prefill=False)
     whole = mv.MiniVLLM(**kw, max_num_batched_tokens=512, enable_chunked_prefill=False, dtype=torch.bfloat16)
@@ -455,22 +449,20 @@ def test_engine_bf16_chunked_prefill_uses_paged_prefill_kernel(mv, device, monke
     calls = {'append': 0, 'rows': 0}
     real_append, real_decode = ops.paged_prefill, ops.paged_decode
     monkeypatch.setattr(ops, 'paged_prefill', lambda *a, **k: calls.__setitem__('append', calls['append'] + 1) or real_append(*a, **k))
-    monkeypatch.setattr(ops, 'paged_decode', lambda *a, **k: calls.__setitem__('rows', calls['rows'] + 1) or real_decode(*a, **k))
+    monkeypatch.setattr(ops, 'paged_decode', lambda q, *a, **k: calls.__setitem__('rows', max(calls['rows'], q.shape[0])) or real_decode(q, *a, **k))
     prompt = [int(x) for x in torch.randint(1, 160, (150,))]
     logits = {}
     for name, eng in (('fp32', ref32), ('whole', whole), ('chunked', chunked)):
         eng.add_request(prompt, max_new_tokens=1, temperature=0.0)
-        f = eng.model.forward_planned
-        cap = []
-        eng.model.forward_planned = lambda *a, _f=f, _c=cap, **k: _c.append(_f(*a, **k)) or _c[-1]
         steps = 0
         while eng.scheduler.has_unfinished:
             eng.step()
             steps += 1
-        logits[name] = cap[-1].float().cpu()
+        logits[name] = eng.last_logits.float().cpu()
         if name == 'chunked':
             assert steps == 4                                     # 40 + 40 + 40 + 30 tokens
-    assert calls['append'] == 3 * 2 and calls['rows'] == 0        # three later chunks x two layers
+    assert calls['append'] == (1 + 1 + 4) * 2                     # one launch per step and layer over the three runs
+    assert calls['rows'] == 8                                     # decode launches cover the 8 request slots, not tokens
     torch.testing.assert_close(logits['whole'], logits['fp32'], atol=0.08, rtol=0.05)
     torch.testing.assert_close(logits['chunked'], logits['fp32'], atol=0.08, rtol=0.05)
     torch.testing.assert_close(logits['chunked'], logits['whole'], atol=0.08, rtol=0.05)

@@ -252,6 +252,63 @@ def test_engine_lookahead_eos_on_a_block_boundary_with_prefix_caching(device):
     assert cached == want
 
 
+def test_engine_follows_weight_edits_and_replacements(device):
+    """Weights changed after steps have been captured: written in place through `.data` (which does
+    not bump a tensor's version counter), and replaced by new tensors.  Both the fused gate/up
+    projection and the captured decode steps must follow -- the results are those of an engine
+    built with the edited weights from the start."""
+    import mini_vllm as mv
+    prompts = [[3, 5, 7, 11, 13], [2, 4, 6], [9, 8, 7, 6, 5, 4, 3, 2, 1]]
+
+    def build():
+        torch.manual_seed(21)
+        eng = mv.MiniVLLM(vocab_size=300, hidden_size=128, num_layers=2, num_heads=4, intermediate_size=256,
+                          num_kv_blocks=64, block_size=8, max_num_seqs=8, max_num_batched_tokens=128,
+                          device='cuda', dtype=torch.float32)
+        for p in eng.model.parameters():
+            p.requires_grad_(False)
+        return eng
+
+    def gen(eng):
+        ids = [eng.add_request(p, max_new_tokens=10, temperature=0.0) for p in prompts]
+        outs = {rid: [] for rid in ids}
+        while eng.scheduler.has_unfinished:
+            for rid, tok in eng.step():
+                outs[rid].append(tok)
+        return [outs[r] for r in ids]
+
+    def edit_in_place(eng):
+        g = torch.Generator(device='cpu').manual_seed(5)
+        ffn = eng.model.layers[0].ffn
+        ffn.gate.weight.data.copy_(torch.randn(ffn.gate.weight.shape, generator=g).to(device) * 0.2)
+        ffn.up.weight.data.mul_(-1.5)
+        eng.model.lm_head.weight.data.add_(torch.randn(eng.model.lm_head.weight.shape, generator=g).to(device) * 0.05)
+
+    def replace(eng):
+        g = torch.Generator(device='cpu').manual_seed(6)
+        ffn = eng.model.layers[1].ffn
+        ffn.up.weight = torch.nn.Parameter(torch.randn(ffn.up.weight.shape, generator=g).to(device) * 0.1,
+                                           requires_grad=False)
+        eng.model.lm_head.weight = torch.nn.Parameter(
+            torch.randn(eng.model.lm_head.weight.shape, generator=g).to(device) * 0.1, requires_grad=False)
+
+    eng = build()
+    base = gen(eng)
+    assert len(eng._graphs) >= 1
+    edit_in_place(eng)
+    after_edit = gen(eng)
+    replace(eng)
+    after_replace = gen(eng)
+
+    fresh = build()
+    edit_in_place(fresh)
+    assert gen(fresh) == after_edit and after_edit != base
+    fresh = build()
+    edit_in_place(fresh)
+    replace(fresh)
+    assert gen(fresh) == after_replace and after_replace != after_edit
+
+
 def test_engine_more_requests_than_slots_equals_eager(device):
     """Continuous batching with a waiting queue: captured decode steps (and steps issued ahead) run
     while every sequence slot is taken, the general path takes over the moment a slot frees.  Every

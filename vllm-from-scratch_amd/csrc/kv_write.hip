@@ -63,14 +63,15 @@ __global__ void __launch_bounds__(256)
 decode_inputs_kernel(int64_t* tok_out, int64_t* pos_out, int64_t* slot_out, int32_t* ctx_out, int32_t* bt_out,
                      const int32_t* packed, const int32_t* tables, const int32_t* prev_ids, int prev_rows,
                      int rows, int table_rows, int width, int block_size, int bs_shift) {
+  const int gw = bt_out ? width : 1;   // threads per row: one per gathered table entry, or one when nothing is gathered
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)rows * width) return;
-  const int r = (int)(idx / width), c = (int)(idx - (int64_t)r * width);
+  if (idx >= (int64_t)rows * gw) return;
+  const int r = (int)(idx / gw), c = (int)(idx - (int64_t)r * gw);
   const int pos = packed[rows + r];
   int src = packed[2 * rows + r];
   src = src < 0 ? 0 : (src >= table_rows ? table_rows - 1 : src);
   const int32_t* row = tables + (int64_t)src * width;
-  bt_out[idx] = row[c];
+  if (bt_out) bt_out[idx] = row[c];
   if (c != 0) return;
   int tok = packed[r];
   if (tok < 0) {
@@ -99,11 +100,11 @@ extern "C" int mi355_decode_step_inputs(int64_t* token_ids, int64_t* positions, 
                                         int32_t prev_rows, int32_t rows, int32_t pool_rows,
                                         int32_t width, int32_t block_size, void* stream) {
   if (rows == 0) return 0;
-  if (!token_ids || !positions || !slots || !context_lens || !block_tables || !packed || !table_pool)
+  if (!token_ids || !positions || !slots || !context_lens || !packed || !table_pool)
     return fail(MI355_EINVAL, "decode_step_inputs: null pointer");
   if (rows < 0 || pool_rows <= 0 || width <= 0 || block_size <= 0 || prev_rows < 0 || (prev_rows > 0 && !prev_ids))
     return fail(MI355_EINVAL, "decode_step_inputs: bad shape");
-  const int64_t threads = (int64_t)rows * width;
+  const int64_t threads = (int64_t)rows * (block_tables ? width : 1);
   hipLaunchKernelGGL(decode_inputs_kernel, dim3((unsigned)ceil_div64(threads, 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), token_ids, positions, slots, context_lens, block_tables,
                      packed, table_pool, prev_ids, prev_rows, rows, pool_rows, width, block_size,

@@ -505,10 +505,11 @@ def silu_mul(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
 
 
 def decode_step_inputs(packed: torch.Tensor, table_pool: torch.Tensor, block_size: int,
-                       prev_ids: Optional[torch.Tensor] = None):
+                       prev_ids: Optional[torch.Tensor] = None, gather_tables: bool = True):
     """packed int32 [3, rows] = (token, position, pool row) -> (token_ids i64 [rows], positions i64
     [rows], slots i64 [rows], context_lens i32 [rows], block_tables i32 [rows, width]).
-    A token entry -1-j is replaced by prev_ids[j] (int32, the previous step's sampled ids)."""
+    A token entry -1-j is replaced by prev_ids[j] (int32, the previous step's sampled ids).
+    gather_tables=False skips the per-row table gather (block_tables is then None)."""
     dev = require_device(packed, table_pool, prev_ids)
     lib = _lib.load()
     if packed.dtype != torch.int32 or packed.dim() != 2 or packed.shape[0] != 3 or not packed.is_contiguous():
@@ -520,10 +521,11 @@ def decode_step_inputs(packed: torch.Tensor, table_pool: torch.Tensor, block_siz
     rows, width = packed.shape[1], table_pool.shape[1]
     i64 = torch.empty((3, rows), dtype=torch.int64, device=dev)
     ctx = torch.empty((rows,), dtype=torch.int32, device=dev)
-    tables = torch.empty((rows, width), dtype=torch.int32, device=dev)
+    tables = torch.empty((rows, width), dtype=torch.int32, device=dev) if gather_tables else None
     with _on(dev):
         rc = lib.mi355_decode_step_inputs(i64[0].data_ptr(), i64[1].data_ptr(), i64[2].data_ptr(), ctx.data_ptr(),
-                                          tables.data_ptr(), packed.data_ptr(), table_pool.data_ptr(),
+                                          tables.data_ptr() if gather_tables else None, packed.data_ptr(),
+                                          table_pool.data_ptr(),
                                           prev_ids.data_ptr() if prev_ids is not None else None,
                                           prev_ids.numel() if prev_ids is not None else 0, rows,
                                           table_pool.shape[0], width, int(block_size), _stream(dev))

@@ -771,20 +771,24 @@ class FFN(nn.Module):
         self.gate = nn.Linear(hidden_size, intermediate_size, bias=False)
         self.up = nn.Linear(hidden_size, intermediate_size, bias=False)
         self.down = nn.Linear(intermediate_size, hidden_size, bias=False)
-        self._gate_up, self._gate_up_version = None, None
+        self._gate_up = None
 
     def _gate_up_weight(self) -> torch.Tensor:
-        """[gate.weight; up.weight] as one matrix, rebuilt when either parameter was replaced or
-        written in place (`weights_version`), so that the two projections are one GEMM."""
-        version = self.weights_version()
-        if self._gate_up_version != version:
-            self._gate_up = torch.cat([self.gate.weight.detach(), self.up.weight.detach()], dim=0)
-            self._gate_up_version = version
-        return self._gate_up
-
-    def weights_version(self) -> tuple:
+        """[gate.weight; up.weight] as one matrix, so that the two projections are one GEMM.
+        There is no second copy of the weights to go stale: the two parameters are re-pointed at
+        the halves of the fused matrix (`param.data = view`), so writes through `.data`,
+        `load_state_dict` and optimiser steps land in it directly.  A parameter that was replaced
+        (module `.to()`, assignment of a new Parameter) no longer points into the matrix, which is
+        then rebuilt from the current values."""
         g, u = self.gate.weight, self.up.weight
-        return (g.data_ptr(), u.data_ptr(), g._version, u._version, g.dtype)
+        f = self._gate_up
+        inter = g.shape[0]
+        if (f is None or f.dtype != g.dtype or f.device != g.device or g.data_ptr() != f.data_ptr()
+                or u.data_ptr() != f[inter:].data_ptr()):
+            f = torch.cat([g.data, u.data], dim=0)
+            g.data, u.data = f[:inter], f[inter:]
+            self._gate_up = f
+        return f
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if _kernel_rows(x, self.gate.weight, self.up.weight):
@@ -884,7 +888,10 @@ class MiniTransformer(nn.Module):
         for i, layer in enumerate(self.layers):
             x, delta = layer.forward_carry(x, delta, positions, (self.k_cache[i], self.v_cache[i]), slot_mapping,
                                            seq_lens, is_prefill, plan)
-        if last is not None and len(last) != x.shape[0]:
+        if isinstance(last, torch.Tensor):           # device-side row selection (captured steps)
+            x = x.index_select(0, last)
+            delta = delta.index_select(0, last) if delta is not None else None
+        elif last is not None and len(last) != x.shape[0]:
             x = x[last]
             delta = delta[last] if delta is not None else None
         if delta is None:
@@ -892,8 +899,18 @@ class MiniTransformer(nn.Module):
         return self.lm_head(self.norm.add_forward(x, delta)[1])
 
     def weights_version(self) -> tuple:
-        """Changes whenever a parameter that a captured step holds a derived copy of does."""
-        return tuple(layer.ffn.weights_version() for layer in self.layers)
+        """Addresses of every parameter and buffer a step reads.  A captured step holds these
+        addresses; it stays valid under in-place edits of the values (a replay reads memory as it
+        is then) and must be dropped when any tensor is replaced by another."""
+        for layer in self.layers:
+            if layer.ffn.gate.weight.is_cuda and not layer.ffn.gate.weight.requires_grad:
+                layer.ffn._gate_up_weight()          # fuses, or re-fuses if a half was replaced (new addresses)
+        slots = self.__dict__.get('_tensor_slots')
+        if slots is None:     # (module, attribute name) of every parameter and buffer: walked once, read every step
+            slots = [(m, n) for m in self.modules() for n in list(m._parameters) + list(m._buffers)
+                     if getattr(m, n) is not None]
+            self.__dict__['_tensor_slots'] = slots
+        return tuple(getattr(m, n).data_ptr() for m, n in slots)
 
 
 # ---------------------------------------------------------------------------
@@ -957,6 +974,84 @@ class DecodeStepGraph:
         self.dev.copy_(self.host[parity & 1], non_blocking=True)
         self.graph.replay()
         return self.logits[:n]
+
+
+def _bucket_tokens(n: int) -> int:
+    """Padded token count of a step: multiples of 64 up to 512, of 256 up to 4096, of 1024 above."""
+    q = 64 if n <= 512 else 256 if n <= 4096 else 1024
+    return max(q, -(-n // q) * q)
+
+
+def _bucket_pow(n: int, base: int, floor: int) -> int:
+    b = floor
+    while b < n:
+        b *= base
+    return b
+
+
+class MixedStep:
+    """A step that contains prompt chunks (with or without decode tokens) at fixed, padded sizes,
+    so that it can be recorded once as a HIP graph and replayed: `tokens` token rows, `slots`
+    request slots, prompt chunks of at most `max_q` tokens, contexts of at most `max_ctx`.
+
+    Token rows are laid out decode tokens first (row j = j-th decode request), prompt chunks after
+    them, padding last.  Everything the kernels need comes from ONE int32 vector staged through
+    pinned memory:
+        [0, 3T)        token id, position (-1 = padding row: no cache write), block-table row   per token row
+        [3T, 3T + 7S)  per request slot: chunk's first token row, chunk length (0 = none), chunk's first
+                       position, chunk's table row | decode context length (0 = none), decode table
+                       row | row of the request's last token (whose logits are wanted)
+    Slot mapping and the table gathers happen on the device.  Decode rows go through the paged
+    decode kernel (rows [0, S): the ones that are not decode rows have context 0, and those that are
+    really prompt tokens are then overwritten), prompt chunks -- first chunks included, their K/V
+    rows are in the cache by then -- through one paged-prefill launch whose grid is sized for the
+    bounds and whose workgroups read their segment's actual length from device memory.
+    With capture=False the same body runs eagerly (same kernels, same launch geometry: an engine
+    without graphs computes bit for bit what the captured engine computes)."""
+
+    def __init__(self, model: "MiniTransformer", tables: DeviceBlockTables, tokens: int, slots: int, max_q: int,
+                 max_ctx: int, capture: bool):
+        dev = tables.device
+        self.model, self.T, self.S, self.max_q, self.max_ctx = model, tokens, slots, max_q, max_ctx
+        self.table_tensor = tables.tables
+        n = 3 * tokens + 7 * slots
+        self.host = torch.zeros((n,), dtype=torch.int32).pin_memory()
+        self.host_np = self.host.numpy()
+        self.dev = torch.zeros((n,), dtype=torch.int32, device=dev)
+        self.dev[tokens:2 * tokens].fill_(-1)
+        self.graph = None
+        if capture:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side), torch.no_grad():      # warm-up: workspaces, GEMM plans
+                for _ in range(2):
+                    self._body()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph), torch.no_grad():
+                self.logits = self._body()
+
+    def _body(self) -> torch.Tensor:
+        T, S = self.T, self.S
+        per_token = self.dev[:3 * T].view(3, T)
+        per_slot = self.dev[3 * T:].view(7, S)
+        tok, pos, slots, _, _ = ops.decode_step_inputs(per_token, self.table_tensor, self.model.block_size,
+                                                       gather_tables=False)
+        plan = AttnPlan(total_tokens=T, causal_index=None, cu_seqlens=None, causal_tokens=0, max_causal_len=0,
+                        paged_index=slice(0, S), paged_tables=self.table_tensor.index_select(0, per_slot[5]),
+                        paged_context=per_slot[4], paged_rows=S, max_context=self.max_ctx,
+                        append_tokens=T, append_tables=self.table_tensor.index_select(0, per_slot[3]),
+                        append_meta=per_slot[0:3], max_append_len=self.max_q, max_append_context=self.max_ctx)
+        return self.model.forward_planned(tok, pos, slots, plan, last=per_slot[6])
+
+    def run(self, nreq: int) -> torch.Tensor:
+        """Logits [nreq, vocab] for the step described in host_np (valid until the next run)."""
+        self.dev.copy_(self.host, non_blocking=True)
+        if self.graph is not None:
+            self.graph.replay()
+            return self.logits[:nreq]
+        with torch.no_grad():
+            return self._body()[:nreq]
 
 
 # ---------------------------------------------------------------------------
@@ -1046,6 +1141,10 @@ class MiniVLLM:
         # replay pure-decode steps as HIP graphs (device-resident engines only)
         self.decode_graphs = decode_graphs and self.device.type == 'cuda' and not reference_compat
         self._graphs: "OrderedDict[tuple, DecodeStepGraph]" = OrderedDict()
+        # steps that hold prompt chunks run at padded sizes through MixedStep (captured when
+        # decode_graphs is on); device-resident engines with true-context attention only
+        self.mixed_steps = self.device.type == 'cuda' and not reference_compat
+        self._mixed: "OrderedDict[tuple, MixedStep]" = OrderedDict()
         self.decode_lookahead = decode_lookahead and self.decode_graphs
         self._inflight: Optional[_InflightDecode] = None   # a decode step issued, its tokens not read yet
         self._launches = 0
@@ -1067,6 +1166,9 @@ class MiniVLLM:
         self.sampler = Sampler()
         self._req_counter = 0
         self._device_tables: Optional[DeviceBlockTables] = None   # created on first use (needs a HIP device)
+        # logits [requests, vocab] of the most recent step, in batch order: a view of a buffer that
+        # the next step may reuse (replayed steps write their logits in place) -- for inspection
+        self.last_logits: Optional[torch.Tensor] = None
 
     def add_request(self, prompt_token_ids: List[int], max_new_tokens: int = 20,
                     temperature: float = 1.0, top_p: float = 1.0) -> str:
@@ -1078,6 +1180,79 @@ class MiniVLLM:
         return req_id
 
     MAX_GRAPHS = 32     # captured decode steps kept per engine (least recently used is dropped)
+    MAX_MIXED = 48      # the same for steps with prompt chunks (more shapes: tokens x slots x chunk x context)
+
+    def _mixed_step(self, tokens: int, nreq: int, max_q: int, max_ctx: int) -> MixedStep:
+        """The (captured) step serving `tokens` token rows of `nreq` requests with prompt chunks up
+        to `max_q` tokens and contexts up to `max_ctx`, at the padded sizes of its bucket."""
+        S = _bucket_pow(nreq, 2, 8)
+        T = max(_bucket_tokens(tokens), S)
+        Q = min(_bucket_pow(max(max_q, 1), 4, 16), T)
+        C = _bucket_pow(max_ctx, 2, 256)
+        tables = self._device_tables
+        key = (T, S, Q, C, tables.tables.data_ptr(), tables.tables.shape[1], self.model.weights_version())
+        step = self._mixed.get(key)
+        if step is None:
+            for stale in [k for k in self._mixed if k[4:] != key[4:]]:
+                del self._mixed[stale]           # block tables, KV buffers or weights were replaced
+            while len(self._mixed) >= self.MAX_MIXED:
+                self._mixed.popitem(last=False)
+            step = self._mixed[key] = MixedStep(self.model, tables, T, S, Q, C, capture=self.decode_graphs)
+        else:
+            self._mixed.move_to_end(key)
+        return step
+
+    def _run_mixed(self, scheduled: List[ScheduledRequest], rows: List[int]) -> Optional[torch.Tensor]:
+        """Logits [len(scheduled), vocab], in scheduled order, of a step through MixedStep; None when
+        the step's contexts are beyond what the paged-prefill kernels serve for this chunk length
+        (the general path then splits such contexts over paged-decode rows)."""
+        decode = [i for i, item in enumerate(scheduled) if not item.is_prefill and len(item.tokens) == 1]
+        is_decode = set(decode)
+        chunks = [i for i in range(len(scheduled)) if i not in is_decode]
+        total = sum(len(item.tokens) for item in scheduled)
+        max_q = max((len(scheduled[i].tokens) for i in chunks), default=1)
+        max_ctx = max(item.start + len(item.tokens) for item in scheduled)
+        cache = self.model.k_cache
+        if not ops.paged_prefill_serves(cache.dtype, cache.shape[-1], self.model.block_size,
+                                        _bucket_pow(max(max_q, 1), 4, 16), _bucket_pow(max_ctx, 2, 256)):
+            return None
+        step = self._mixed_step(total, len(scheduled), max_q, max_ctx)
+        T, S = step.T, step.S
+        buf = step.host_np
+        per_token = buf[:3 * T].reshape(3, T)
+        per_slot = buf[3 * T:].reshape(7, S)
+        per_token[0] = 0
+        per_token[1] = -1
+        per_token[2] = 0
+        per_slot[:] = 0
+        for j, i in enumerate(decode):
+            item = scheduled[i]
+            per_token[0, j] = item.tokens[0]
+            per_token[1, j] = item.start
+            per_token[2, j] = rows[i]
+            per_slot[4, j] = item.start + 1
+            per_slot[5, j] = rows[i]
+            per_slot[6, i] = j
+        at = len(decode)
+        for s_idx, i in enumerate(chunks):
+            item = scheduled[i]
+            req, n, start = item.request, len(item.tokens), item.start
+            if item.is_prefill:
+                prompt = getattr(req, '_prompt_array', None)
+                if prompt is None:
+                    prompt = req._prompt_array = np.asarray(req.prompt_token_ids, dtype=np.int64)
+                per_token[0, at:at + n] = prompt[start:start + n]
+            else:
+                per_token[0, at:at + n] = item.tokens
+            per_token[1, at:at + n] = np.arange(start, start + n, dtype=np.int32)
+            per_token[2, at:at + n] = rows[i]
+            per_slot[0, s_idx] = at
+            per_slot[1, s_idx] = n
+            per_slot[2, s_idx] = start
+            per_slot[3, s_idx] = rows[i]
+            per_slot[6, i] = at + n - 1
+            at += n
+        return step.run(len(scheduled))
 
     def _decode_graph(self, nseq: int, max_context: int) -> DecodeStepGraph:
         """The captured step serving `nseq` sequences with contexts up to `max_context`: batch
@@ -1116,7 +1291,7 @@ class MiniVLLM:
         parity = self._launches & 1
         self._launches += 1
         n = len(batch)
-        logits = self._decode_graph(n, max(positions) + 1).run(tokens, positions, rows, parity)
+        logits = self.last_logits = self._decode_graph(n, max(positions) + 1).run(tokens, positions, rows, parity)
         ids = self.sampler.sample_device(logits, batch, out=self._ids_dev)
         self._ids_host[parity][:n].copy_(ids, non_blocking=True)
         self._ids_done[parity].record()
@@ -1184,6 +1359,17 @@ class MiniVLLM:
             self._inflight = nxt
         return [(req.request_id, tok) for req, tok in zip(batch, next_tokens)]
 
+    def _mixed_supported(self) -> bool:
+        """MixedStep needs the paged-prefill kernels for this model's dtype and head_dim, device-
+        resident weights and KV buffers, and inference-only parameters."""
+        ok = self.__dict__.get('_mixed_ok')
+        if ok is None:
+            cache = self.model.k_cache
+            ok = self._mixed_ok = (cache.is_cuda and self.model.embedding.weight.is_cuda
+                                   and ops.paged_prefill_supported(cache.dtype, cache.shape[-1])
+                                   and cache.dtype == self.model.embedding.weight.dtype)
+        return ok
+
     def step(self):
         """One engine step; returns [(request_id, new_token)] for every request that
         produced a token (decode steps and the final chunk of a prompt)."""
@@ -1197,6 +1383,20 @@ class MiniVLLM:
         seq_lens = [len(item.tokens) for item in scheduled]
         prefill_flags = [item.is_prefill for item in scheduled]
         requests = [item.request for item in scheduled]
+        if self.mixed_steps and self._mixed_supported():
+            if self._device_tables is None:
+                self._device_tables = DeviceBlockTables(_compute_device(self.model.k_cache),
+                                                        rows=max(8, self.scheduler.max_num_seqs))
+            logits = self._run_mixed(scheduled, self._device_tables.sync(requests))
+            if logits is not None:
+                self.last_logits = logits
+                next_tokens = self.sampler.sample(logits, requests)
+                self.scheduler.update(scheduled, next_tokens)
+                for req in requests:
+                    if req.is_finished:
+                        self._device_tables.release(req.request_id)
+                return [(item.request.request_id, tok) for item, tok in zip(scheduled, next_tokens)
+                        if not (item.is_prefill and item.request.is_prefill)]
         # the step's flattened (token, position, slot) vectors, by array arithmetic per request:
         # positions are consecutive from item.start, slot = block_table[pos // bs] * bs + pos % bs
         bs = self.scheduler.block_size
@@ -1236,6 +1436,7 @@ class MiniVLLM:
             logits = self.model(step_inputs[0], step_inputs[1], step_inputs[2], seq_lens, prefill_flags,
                                 positions_host=host_inputs[1], reference_compat=self.reference_compat,
                                 device_tables=self._device_tables, table_rows=rows)
+        self.last_logits = logits
         next_tokens = self.sampler.sample(logits, requests)
         self.scheduler.update(scheduled, next_tokens)
         if self._device_tables is not None:
