@@ -308,7 +308,9 @@ class Scheduler:
                 batch.append(self._emit(req, req.prompt_token_ids[first:first + want], first, True))
                 budget -= want
             else:
-                if not room() or not self._ensure_blocks(req, 1):
+                # (the table usually covers the next position already: skip the call then)
+                if not room() or (len(req.block_table) * self.block_size <= req.num_computed_tokens
+                                  and not self._ensure_blocks(req, 1)):
                     continue
                 last = req.output_token_ids[-1:] or req.prompt_token_ids[-1:]
                 batch.append(self._emit(req, last, req.num_computed_tokens, False))
@@ -906,11 +908,11 @@ class MiniTransformer(nn.Module):
             if layer.ffn.gate.weight.is_cuda and not layer.ffn.gate.weight.requires_grad:
                 layer.ffn._gate_up_weight()          # fuses, or re-fuses if a half was replaced (new addresses)
         slots = self.__dict__.get('_tensor_slots')
-        if slots is None:     # (module, attribute name) of every parameter and buffer: walked once, read every step
-            slots = [(m, n) for m in self.modules() for n in list(m._parameters) + list(m._buffers)
-                     if getattr(m, n) is not None]
+        if slots is None:     # (holding dict, name) of every parameter and buffer: walked once, read every step
+            slots = [(d, n) for m in self.modules() for d in (m._parameters, m._buffers) for n in d
+                     if d[n] is not None]
             self.__dict__['_tensor_slots'] = slots
-        return tuple(getattr(m, n).data_ptr() for m, n in slots)
+        return tuple([d[n].data_ptr() for d, n in slots])
 
 
 # ---------------------------------------------------------------------------
@@ -1225,15 +1227,17 @@ class MiniVLLM:
         per_token[1] = -1
         per_token[2] = 0
         per_slot[:] = 0
-        for j, i in enumerate(decode):
-            item = scheduled[i]
-            per_token[0, j] = item.tokens[0]
-            per_token[1, j] = item.start
-            per_token[2, j] = rows[i]
-            per_slot[4, j] = item.start + 1
-            per_slot[5, j] = rows[i]
-            per_slot[6, i] = j
-        at = len(decode)
+        nd = len(decode)
+        if nd:
+            starts = np.fromiter((scheduled[i].start for i in decode), dtype=np.int32, count=nd)
+            drows = np.fromiter((rows[i] for i in decode), dtype=np.int32, count=nd)
+            per_token[0, :nd] = np.fromiter((scheduled[i].tokens[0] for i in decode), dtype=np.int32, count=nd)
+            per_token[1, :nd] = starts
+            per_token[2, :nd] = drows
+            per_slot[4, :nd] = starts + 1
+            per_slot[5, :nd] = drows
+            per_slot[6, decode] = np.arange(nd, dtype=np.int32)
+        at = nd
         for s_idx, i in enumerate(chunks):
             item = scheduled[i]
             req, n, start = item.request, len(item.tokens), item.start
