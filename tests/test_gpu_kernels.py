@@ -634,8 +634,9 @@ def test_prefill_varlen_packed(ops, device, dtype):
     (3, 1, 256, [40, 9]),
 ])
 def test_prefill_fp32_row_groups_match_oracle_and_single_rows(ops, device, shape):
-    """fp32 prompts: one query row per lane at head_dim 32 / 64 / 128, elsewhere the decode-shaped kernel with
-    eight consecutive query rows per wave sharing each K/V load; both meet the oracle and the
+    """fp32 prompts: the fp32 matrix instruction at head_dim 32 / 64 / 128 (the default there), the
+    vector-ALU kernel with one query row per lane, elsewhere the decode-shaped kernel with eight
+    consecutive query rows per wave sharing each K/V load; all meet the oracle and the
     one-row-per-workgroup form of the decode-shaped kernel."""
     Hq, Hkv, D, lens = shape
     rng = np.random.default_rng(sum(lens) + D)
@@ -644,15 +645,69 @@ def test_prefill_fp32_row_groups_match_oracle_and_single_rows(ops, device, shape
     cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
     want = orc.varlen_causal_attention(q.numpy(), k.numpy(), v.numpy(), cu, dtype=np.float64)
     args = (q.to(device), k.to(device), v.to(device), torch.from_numpy(cu).to(device), max(lens))
-    default = ops.prefill_causal(*args).cpu().numpy()          # head_dim 32 / 64 / 128: one query row per lane
-    with ops.debug_knob('MI355_PREFILL_F32_TILED', 0):
-        grouped = ops.prefill_causal(*args).cpu().numpy()
-        with ops.debug_knob('MI355_PREFILL_ROW_GROUPS', 0):
-            single = ops.prefill_causal(*args).cpu().numpy()
-    for got in (default, grouped, single):
+    default = ops.prefill_causal(*args).cpu().numpy()          # head_dim 32 / 64 / 128: matrix cores
+    with ops.debug_knob('MI355_PREFILL_F32_MFMA', 0):
+        per_lane = ops.prefill_causal(*args).cpu().numpy()     # head_dim 32 / 64 / 128: one query row per lane
+        with ops.debug_knob('MI355_PREFILL_F32_TILED', 0):
+            grouped = ops.prefill_causal(*args).cpu().numpy()
+            with ops.debug_knob('MI355_PREFILL_ROW_GROUPS', 0):
+                single = ops.prefill_causal(*args).cpu().numpy()
+    for got in (default, per_lane, grouped, single):
         np.testing.assert_allclose(got, want, **F32_TOL)
     np.testing.assert_allclose(grouped, single, atol=2e-6, rtol=1e-5)
-    np.testing.assert_allclose(default, single, atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(per_lane, single, atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(default, single, atol=4e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize('D', [32, 64, 128])
+def test_prefill_fp32_matrix_cores_long_and_growing_scores(ops, device, D):
+    """The fp32 matrix-core kernel over several tiles per row (sequence lengths around the 128-row
+    workgroup and 64-key tile borders, grouped heads, strided views), with scores that rise along
+    the sequence by about 200 log2 units so that the deferred softmax reference moves many times;
+    packed and paged entry points.  Tolerance: atol 5e-5 (the reference's 1e-5 bar is held on ordinary
+    data by the golden and shape tests; here a row's scores span 200 log2 units and its weights pass
+    through several moves of the reference, each an exp2 of about an ulp)."""
+    rng = np.random.default_rng(D)
+    Hq, Hkv, BS = 4, 2, 16
+    lens = [600, 129, 64, 1, 257]
+    T = sum(lens)
+    q = rng.standard_normal((T, Hq, D), dtype=np.float32) * 0.2
+    k = rng.standard_normal((T, Hkv, D), dtype=np.float32) * 0.2
+    v = rng.standard_normal((T, Hkv, D), dtype=np.float32)
+    q[:600, :, 0] = 4.0
+    ramp = np.arange(600, dtype=np.float32) * 0.45
+    ramp[300:] += 40.0
+    ramp[437] += 30.0
+    k[:600, :, 0] = ramp[:, None] * math.sqrt(D) / 4.0 * 0.25
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    want = orc.varlen_causal_attention(q, k, v, cu, dtype=np.float64)
+    tq, tk, tv = (torch.from_numpy(a).to(device) for a in (q, k, v))
+    got = ops.prefill_causal(tq, tk, tv, torch.from_numpy(cu).to(device), max(lens))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=5e-5, rtol=1e-4)
+    # the same rows as chunks over a block cache: sequence s = a prefix of pre[s] cached tokens + the rest as queries
+    pre = [300, 0, 17, 0, 100]
+    per = (max(lens) + BS - 1) // BS
+    NB = len(lens) * per + 3
+    bt = rng.permutation(NB)[:len(lens) * per].reshape(len(lens), per).astype(np.int32)
+    cache = np.zeros((2, NB, Hkv, BS, D), dtype=np.float32)
+    for s, n in enumerate(lens):
+        for t in range(n):
+            cache[0, bt[s, t // BS], :, t % BS] = k[cu[s] + t]
+            cache[1, bt[s, t // BS], :, t % BS] = v[cu[s] + t]
+    tc = torch.from_numpy(cache).to(device)
+    i32 = lambda x: torch.tensor(x, dtype=torch.int32, device=device)
+    q0 = [int(cu[s]) + pre[s] for s in range(len(lens))]
+    nq = [lens[s] - pre[s] for s in range(len(lens))]
+    out = torch.zeros_like(tq)
+    ops.paged_prefill(tq, tc[0], tc[1], torch.from_numpy(bt).to(device), i32(q0), i32(nq), i32(pre), max(nq), max(lens),
+                      out=out)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    for s in range(len(lens)):
+        a, b = q0[s], int(cu[s + 1])
+        np.testing.assert_allclose(got[a:b], want[a:b], atol=5e-5, rtol=1e-4)
+        assert not got[int(cu[s]):a].any()                   # rows outside every segment stay untouched
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])

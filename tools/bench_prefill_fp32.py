@@ -20,9 +20,13 @@ k = torch.randn(T, Hkv, D, device=dev, dtype=dtype)
 v = torch.randn(T, Hkv, D, device=dev, dtype=dtype)
 cu = torch.arange(0, T + 1, L, dtype=torch.int32, device=dev)
 flops = 4.0 * nseq * Hq * D * L * (L + 1) / 2
-ops._lib.load().mi355_debug_set_knob(b'MI355_PREFILL_VALU', 1)
 outs = {}
-for name, tiled, env in (('one query row per lane', '1', '1'), ('row groups of 8', '0', '1'), ('one row per workgroup', '0', '0')):
+for name, mfma, tiled, env in (('matrix cores (fp32 MFMA)', 1, '1', '1'), ('one query row per lane', 0, '1', '1'),
+                               ('row groups of 8', 0, '0', '1'), ('one row per workgroup', 0, '0', '0')):
+    if mfma and dtype != torch.float32:
+        continue
+    ops._lib.load().mi355_debug_set_knob(b'MI355_PREFILL_VALU', 0 if mfma else 1)
+    ops._lib.load().mi355_debug_set_knob(b'MI355_PREFILL_F32_MFMA', mfma)
     ops._lib.load().mi355_debug_set_knob(b'MI355_PREFILL_F32_TILED', int(tiled))
     ops._lib.load().mi355_debug_set_knob(b'MI355_PREFILL_ROW_GROUPS', int(env))
     for _ in range(2):

@@ -35,6 +35,7 @@ enum Knob {
   kKnobPrefillWaves,      // MI355_PREFILL_WAVES       0: planned; 4 or 8 waves per prompt workgroup
   kKnobMlaManyHeads,      // MI355_MLA_MANY_HEADS      1: 64 heads per MLA workgroup above 16 heads
   kKnobMlaTargetWgs,      // MI355_MLA_TARGET_WGS      0: planned; else workgroups an MLA launch aims for
+  kKnobPrefillF32Mfma,    // MI355_PREFILL_F32_MFMA    1: fp32 prompts (head_dim 32 / 64 / 128) on the fp32 matrix instruction
   kKnobCount
 };
 int knob(Knob k);
@@ -53,6 +54,17 @@ int prefill_mfma_paged_launch(void* out, const void* q, int64_t q_stride_tok, co
                               int Hkv, int D, int block_size, int max_blocks, int num_blocks, int max_context,
                               int64_t s_blk, int64_t s_head, int64_t s_tok, float scale, int dtype,
                               hipStream_t stream);
+
+// fp32 causal prefill on the matrix cores (prefill_mfma_f32.hip): head_dim 32 / 64 / 128, packed and paged.
+bool prefill_mfma_f32_supported(int dtype, int D);
+int prefill_mfma_f32_launch(void* out, const void* q, const void* k, const void* v, int64_t q_stride_tok,
+                            int64_t kv_stride_tok, const int32_t* cu_seqlens, int nseq, int max_seqlen, int Hq,
+                            int Hkv, int D, float scale, hipStream_t stream);
+int prefill_mfma_f32_paged_launch(void* out, const void* q, int64_t q_stride_tok, const void* k_cache,
+                                  const void* v_cache, const int32_t* block_tables, const int32_t* seg_q0,
+                                  const int32_t* seg_len, const int32_t* seg_pos0, int nseg, int max_q_len, int Hq,
+                                  int Hkv, int D, int block_size, int max_blocks, int num_blocks, int max_context,
+                                  int64_t s_blk, int64_t s_head, int64_t s_tok, float scale, hipStream_t stream);
 
 // fp32 causal prefill with one query row per lane (prefill_f32.hip): head_dim 32 / 64 / 128.
 bool prefill_f32_supported(int dtype, int D);

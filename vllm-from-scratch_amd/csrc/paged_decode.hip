@@ -798,6 +798,17 @@ extern "C" int mi355_paged_prefill(void* out, const void* q, int64_t q_stride_to
     return fail(MI355_EINVAL, "paged_prefill: bad shape");
   const int gq = Hq / Hkv;
   if ((int64_t)max_context > (int64_t)max_blocks * block_size) max_context = max_blocks * block_size;
+  // fp32 chunks of many query tokens at head_dim 32 / 64 / 128: the fp32 matrix-core flash kernel
+  if (prefill_mfma_f32_supported(dtype, D) && scale > 0.f && max_q_len >= knob(kKnobPagedPrefillMinQ) &&
+      knob(kKnobPrefillF32Mfma) && kv_stride_block > 0 && kv_stride_head >= 0 && kv_stride_tok > 0 &&
+      kv_stride_block % 4 == 0 && kv_stride_head % 4 == 0 && kv_stride_tok % 4 == 0 && q_stride_tok % 4 == 0 &&
+      q_stride_tok >= (int64_t)Hq * D && kv_stride_block < (1LL << 31) &&
+      (kv_stride_tok * (int64_t)block_size + (int64_t)Hkv * kv_stride_head + D) * 4 < (1LL << 32) &&
+      !(((uintptr_t)out | (uintptr_t)q | (uintptr_t)k_cache | (uintptr_t)v_cache) & 15))
+    return prefill_mfma_f32_paged_launch(out, q, q_stride_tok, k_cache, v_cache, block_tables, seg_q_start, seg_len,
+                                         seg_pos0, nseg, max_q_len, Hq, Hkv, D, block_size, max_blocks, num_blocks,
+                                         max_context, kv_stride_block, kv_stride_head, kv_stride_tok, scale,
+                                         static_cast<hipStream_t>(stream));
   if (!decode_gqa_supported(dtype, D, 4))   // fp32, head dims off the matrix-core path: VALU kernel, row groups
     return paged_prefill_rows(out, q, q_stride_tok, k_cache, v_cache, block_tables, seg_q_start, seg_len, seg_pos0,
                               nseg, max_q_len, Hq, Hkv, D, block_size, max_blocks, num_blocks, max_context,
@@ -919,6 +930,12 @@ extern "C" int mi355_prefill_causal(void* out, const void* q, const void* k, con
       !knob(kKnobPrefillValu))
     return prefill_mfma_launch(out, q, k, v, q_stride_tok, kv_stride_tok, cu_seqlens, nseq, total_tokens,
                                max_seqlen, Hq, Hkv, D, scale, dtype, static_cast<hipStream_t>(stream));
+  // fp32 at head_dim 32 / 64 / 128: the fp32 matrix instruction (prefill_mfma_f32.hip; exact fp32
+  // products).  MI355_PREFILL_F32_MFMA=0 keeps the vector-ALU kernels below (A/B measurements).
+  if (prefill_mfma_f32_supported(dtype, D) && scale > 0.f && kv_stride_tok < (1LL << 24) &&
+      knob(kKnobPrefillF32Mfma) && !knob(kKnobPrefillValu))
+    return prefill_mfma_f32_launch(out, q, k, v, q_stride_tok, kv_stride_tok, cu_seqlens, nseq, max_seqlen, Hq, Hkv,
+                                   D, scale, static_cast<hipStream_t>(stream));
   // fp32 at head_dim 32 / 64 / 128: one query row per lane (prefill_f32.hip).
   // MI355_PREFILL_F32_TILED=0 keeps the decode-shaped kernel below (A/B measurements).
   if (prefill_f32_supported(dtype, D) && knob(kKnobPrefillF32Tiled))
