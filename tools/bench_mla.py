@@ -1,5 +1,5 @@
 """Time mi355_mla_decode at the MLA configuration of BASELINE.json (kv_lora_rank=512, rope 64, ctx 4096).
-Usage: python tools/bench_mla.py [batch heads ctx]"""
+Usage: python tools/bench_mla.py [batch heads ctx [float32]]"""
 import os
 import sys
 
@@ -7,20 +7,22 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 import torch
 from mi355_paged import ops
 
-B, H, S = ([int(x) for x in sys.argv[1:]] + [64, 16, 4096])[:3]
+B, H, S = ([int(x) for x in sys.argv[1:4]] + [64, 16, 4096])[:3]
+DT = getattr(torch, sys.argv[4]) if len(sys.argv) > 4 else torch.bfloat16
+ES = 4 if DT == torch.float32 else 2
 R, P = 512, 64
 dev = torch.device('cuda', 0)
 g = torch.Generator(device=dev).manual_seed(0)
 sets = 3
-pools = [((torch.randn((B, S, R), generator=g, device=dev)).to(torch.bfloat16),
-          (torch.randn((B, S, P), generator=g, device=dev)).to(torch.bfloat16)) for _ in range(sets)]
-q = (torch.randn((B, H, R + P), generator=g, device=dev) * 0.3).to(torch.bfloat16)
+pools = [((torch.randn((B, S, R), generator=g, device=dev)).to(DT),
+          (torch.randn((B, S, P), generator=g, device=dev)).to(DT)) for _ in range(sets)]
+q = (torch.randn((B, H, R + P), generator=g, device=dev) * 0.3).to(DT)
 pos = torch.arange(S, device=dev, dtype=torch.float32)
 inv = 1.0 / (10000.0 ** (torch.arange(0, P, 2, device=dev).float() / P))
 ang = torch.outer(pos, inv)
 cos, sin = torch.cat([ang, ang], -1).cos(), torch.cat([ang, ang], -1).sin()
 ctx = torch.full((B,), S, dtype=torch.int32, device=dev)
-nbytes = B * S * (R + P) * 2 + B * H * (R + P) * 2 + B * H * R * 4
+nbytes = B * S * (R + P) * ES + B * H * (R + P) * ES + B * H * R * 4
 flops = 2.0 * B * H * S * (R + P + R)
 for tgt in [int(x) for x in os.environ.get('MLA_TARGETS', '0,1024,2048,0').split(',')]:
     ops._lib.load().mi355_debug_set_knob(b'MI355_MLA_TARGET_WGS', tgt)      # 0 = the library's own plan
@@ -35,5 +37,5 @@ for tgt in [int(x) for x in os.environ.get('MLA_TARGETS', '0,1024,2048,0').split
             ev[i - 5][1].record()
     torch.cuda.synchronize()
     ms = sorted(a.elapsed_time(b) for a, b in ev)[n // 2]
-    print(f"mla_decode B={B} H={H} ctx={S} R={R} P={P} target={tgt or 'default'}: {ms * 1e3:.1f} us  "
+    print(f"mla_decode {str(DT).split('.')[-1]} B={B} H={H} ctx={S} R={R} P={P} target={tgt or 'default'}: {ms * 1e3:.1f} us  "
           f"{nbytes / ms / 1e6:.0f} GB/s ({nbytes / ms / 1e6 / 80:.1f}% of 8 TB/s)  {flops / ms / 1e9:.1f} TFLOP/s", flush=True)

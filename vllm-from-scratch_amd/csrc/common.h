@@ -55,6 +55,14 @@ int prefill_mfma_paged_launch(void* out, const void* q, int64_t q_stride_tok, co
                               int64_t s_blk, int64_t s_head, int64_t s_tok, float scale, int dtype,
                               hipStream_t stream);
 
+// fp32 latent-space MLA attention on the fp32 matrix instruction (mla_decode_f32.hip).
+bool mla_f32_supported(int R, int P);
+int mla_f32_launch(float* out, const float* q, int64_t q_stride_row, const float* c_kv, int64_t ckv_stride_seq,
+                   int64_t ckv_stride_tok, const float* k_rope, int64_t krope_stride_seq, int64_t krope_stride_tok,
+                   const float* cos_table, const float* sin_table, int table_len, const int32_t* context_lens,
+                   const int32_t* row_seq, int rows, int H, int R, int P, int max_context, float scale,
+                   hipStream_t stream);
+
 // fp32 causal prefill on the matrix cores (prefill_mfma_f32.hip): head_dim 32 / 64 / 128, packed and paged.
 bool prefill_mfma_f32_supported(int dtype, int D);
 int prefill_mfma_f32_launch(void* out, const void* q, const void* k, const void* v, int64_t q_stride_tok,

@@ -843,6 +843,7 @@ using namespace mi355;
 
 extern "C" size_t mi355_mla_decode_workspace_bytes(int32_t rows, int32_t H, int32_t R, int32_t P,
                                                    int32_t max_context, int32_t dtype) {
+  if (dtype == MI355_F32) return 0;   // the fp32 kernel walks a row's context in one workgroup: no partials
   MlaPlan pl;
   if (mla_plan(rows, H, R, P, max_context, dtype, &pl)) return 0;
   return pl.ws_bytes;
@@ -858,6 +859,21 @@ extern "C" int mi355_mla_decode(float* out, const void* q, int64_t q_stride_row,
   if (rows == 0) return 0;
   if (!out || !q || !c_kv || !k_rope || !cos_table || !sin_table || !context_lens)
     return fail(MI355_EINVAL, "mla_decode: null pointer argument");
+  if (dtype == MI355_F32) {
+    if (rows < 0 || H <= 0 || max_context < 0 || table_len <= 0) return fail(MI355_EINVAL, "mla_decode: bad shape");
+    if (!mla_f32_supported(R, P))
+      return fail(MI355_EUNSUPPORTED, "mla_decode (fp32): kv_lora_rank %d / rope dim %d outside {32,64,128} x {8,16,32,64} and {256,512} x {32,64}",
+                  R, P);
+    if (q_stride_row % 4 || ckv_stride_tok % 4 || ckv_stride_seq % 4 || q_stride_row < (int64_t)H * (R + P) ||
+        ckv_stride_tok < R || krope_stride_tok < P)
+      return fail(MI355_EINVAL, "mla_decode: strides must keep rows 16-byte aligned");
+    if (((uintptr_t)out | (uintptr_t)q | (uintptr_t)c_kv) & 15)
+      return fail(MI355_EINVAL, "mla_decode: tensors must be 16-byte aligned");
+    return mla_f32_launch(out, static_cast<const float*>(q), q_stride_row, static_cast<const float*>(c_kv),
+                          ckv_stride_seq, ckv_stride_tok, static_cast<const float*>(k_rope), krope_stride_seq,
+                          krope_stride_tok, cos_table, sin_table, table_len, context_lens, row_seq, rows, H, R, P,
+                          max_context, scale, static_cast<hipStream_t>(stream));
+  }
   MlaPlan pl;
   if (int rc = mla_plan(rows, H, R, P, max_context, dtype, &pl)) return rc;
   if (table_len <= 0) return fail(MI355_EINVAL, "mla_decode: empty cos/sin table");

@@ -344,13 +344,19 @@ def slot_mapping(block_tables: torch.Tensor, starts: torch.Tensor, cu_tokens: to
     return out
 
 
+def mla_fp32_supported(R: int, P: int) -> bool:
+    """Shapes the fp32 MLA kernel serves (the 16-bit kernels take every R in {32..512}, P <= 64)."""
+    return (R in (32, 64, 128) and P in (8, 16, 32, 64)) or (R in (256, 512) and P in (32, 64))
+
+
 def mla_decode(q: torch.Tensor, c_kv: torch.Tensor, k_rope: torch.Tensor, cos: torch.Tensor,
                sin: torch.Tensor, context_lens: torch.Tensor, max_context: int, scale: float,
                row_seq: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Latent-space MLA attention.
 
     q [rows, H, R + P] (absorbed nope query | rotated rope query); c_kv [S_seqs, S, R] and
-    k_rope [S_seqs, S, P] (un-rotated) in q's 16-bit dtype; cos / sin [table_len, P] fp32;
+    k_rope [S_seqs, S, P] (un-rotated) in q's dtype (bf16 / fp16, or fp32 where
+    mla_fp32_supported(R, P)); cos / sin [table_len, P] fp32;
     context_lens [rows] int32; row_seq [rows] int32 or None.  Returns [rows, H, R] fp32.
     """
     dev = require_device(q, c_kv, k_rope, cos, sin, context_lens, row_seq)
@@ -362,7 +368,7 @@ def mla_decode(q: torch.Tensor, c_kv: torch.Tensor, k_rope: torch.Tensor, cos: t
     if DQ != R + P:
         raise ValueError(f"q last dim {DQ} != kv_lora_rank {R} + rope dim {P}")
     if c_kv.dtype != q.dtype or k_rope.dtype != q.dtype:
-        raise TypeError("q, c_kv and k_rope must share a 16-bit dtype")
+        raise TypeError("q, c_kv and k_rope must share one dtype")
     if q.stride(2) != 1 or q.stride(1) != DQ:
         q = q.contiguous()
     if c_kv.stride(2) != 1:

@@ -117,7 +117,13 @@ class _LatentAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q_cat, c_kv, k_rope, cos, sin, context, row_seq, max_context, scale):
         dev = _compute_device(q_cat)
-        kdtype = torch.bfloat16 if q_cat.dtype == torch.bfloat16 else torch.float16
+        # fp32 modules keep fp32 operands (fp32 matrix instruction: exact products, fp32 weights) where
+        # that kernel serves the shape; otherwise, and for 16-bit modules, the 16-bit kernels run --
+        # bf16 for everything but fp16 modules: un-normalised projections can exceed fp16's range
+        if q_cat.dtype == torch.float32 and ops.mla_fp32_supported(c_kv.shape[-1], k_rope.shape[-1]):
+            kdtype = torch.float32
+        else:
+            kdtype = torch.float16 if q_cat.dtype == torch.float16 else torch.bfloat16
         out = ops.mla_decode(q_cat.detach().to(device=dev, dtype=kdtype), c_kv.detach().to(device=dev, dtype=kdtype),
                              k_rope.detach().to(device=dev, dtype=kdtype), cos.to(dev), sin.to(dev),
                              context.to(device=dev, dtype=torch.int32), max_context, scale,
