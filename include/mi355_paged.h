@@ -210,8 +210,7 @@ int mi355_slot_mapping(int64_t* out_slots, const int32_t* block_tables, const in
  *   q         [rows, H, R+P] (q_stride_row elements between rows), bf16 / f16 -- or fp32 (dtype
  *             MI355_F32, then c_kv and k_rope are fp32 too): the fp32 matrix instruction keeps
  *             every product exact, for callers that compare with an fp32 reference; it serves
- *             R in {32,64,128} with P in {8,16,32,64} and R in {256,512} with P in {32,64}, and
- *             needs no workspace
+ *             R in {32,64,128} with P in {8,16,32,64} and R in {256,512} with P in {32,64}
  *   c_kv      row of token t of sequence s at  s*ckv_stride_seq + t*ckv_stride_tok   (R elements)
  *   k_rope    likewise with the krope strides                                           (P elements)
  *   context_lens [rows]; row_seq [rows] = cache sequence each row reads (NULL: row i reads i) --

@@ -57,6 +57,8 @@ def test_mla_decode_kernel(ops, device, shape, dtype):
     # seqs, H, R, P, max_ctx -- one-wave kernel (rank <= 128) and four-wave kernel (rank >= 256)
     (3, 4, 32, 8, 40), (2, 8, 64, 16, 100), (2, 16, 128, 32, 333), (2, 20, 128, 64, 77), (1, 3, 32, 64, 17),
     (2, 16, 512, 64, 700), (1, 20, 256, 64, 50), (3, 17, 512, 32, 95), (2, 8, 256, 32, 1), (1, 40, 512, 64, 260),
+    # few rows over long contexts: token splits + the merge kernel
+    (2, 16, 512, 64, 3000), (1, 8, 64, 16, 2000), (3, 4, 128, 32, 1500),
 ])
 def test_mla_decode_fp32_kernel(ops, device, shape):
     seqs, H, R, P, max_ctx = shape

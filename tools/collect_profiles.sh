@@ -9,17 +9,12 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 step() { echo "== $*" >&2; }
 
-step bench.py
-timeout -k 10 300 python3 bench.py > "$OUT/bench_line.json" 2> "$OUT/bench.err"
-timeout -k 10 300 python3 bench.py --config c2 --no-cpu-baseline > "$OUT/bench_line_c2.json" 2>> "$OUT/bench.err"
-
-step kernel trace of bench.py
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_bench" -o bench -- \
-  python3 bench.py --steps 100 --no-cpu-baseline > "$OUT/bench_line_under_rocprof.json" 2> "$OUT/trace_bench.log"
+step headline: bench lines, kernel traces and HBM-traffic counters of the metric config and config 2
+tools/collect_headline.sh "$TAG" > "$OUT/headline.txt" 2> "$OUT/headline.err"
 
 step kernel trace of the small decode config, the grouped-query, MLA and prefill benches
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c2" -o c2 -- \
-  python3 tools/tune_decode.py c2 256 > "$OUT/c2_under_rocprof.txt" 2> "$OUT/trace_c2.log"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c2tune" -o c2tune -- \
+  python3 tools/tune_c2.py c2 > "$OUT/c2_under_rocprof.txt" 2> "$OUT/trace_c2tune.log"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_gqa" -o gqa -- \
   python3 tools/bench_gqa.py > "$OUT/gqa_under_rocprof.txt" 2> "$OUT/trace_gqa.log"
 MLA_TARGETS=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_mla" -o mla -- \
@@ -29,15 +24,14 @@ BENCH_MFMA_ONLY=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-fo
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_paged_prefill" -o pp -- \
   python3 tools/bench_paged_prefill.py > "$OUT/paged_prefill_under_rocprof.txt" 2> "$OUT/trace_paged_prefill.log"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_engine" -o engine -- \
-  python3 tools/profile_engine.py 256 512 64 > "$OUT/engine_under_rocprof.txt" 2> "$OUT/trace_engine.log"
+  python3 tools/bench_engine_mixed.py 512 128 2048 > "$OUT/engine_under_rocprof.txt" 2> "$OUT/trace_engine.log"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_prefill_f32" -o prefill_f32 -- \
+  python3 tools/bench_prefill_fp32.py 16 2048 8 8 64 > "$OUT/prefill_f32_under_rocprof.txt" 2> "$OUT/trace_prefill_f32.log"
 
-step counters: HBM traffic of the decode kernel, MFMA activity of the prefill kernel
-timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o fetch -- \
-  python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2> "$OUT/pmc_fetch.log"
-timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o write -- \
-  python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2> "$OUT/pmc_write.log"
+step counters: MFMA activity of the prefill kernels, MLA
 BENCH_MFMA_ONLY=1 tools/pmc_sq.sh "$OUT/pmc_prefill_d128" prefill_mfma tools/bench_prefill.py 4 8192 32 8 128 > "$OUT/pmc_prefill_d128.txt"
 BENCH_MFMA_ONLY=1 tools/pmc_sq.sh "$OUT/pmc_prefill_d64" prefill_mfma tools/bench_prefill.py 2 16384 8 8 64 > "$OUT/pmc_prefill_d64.txt"
+tools/pmc_sq.sh "$OUT/pmc_prefill_f32" prefill_mfma_f32 tools/bench_prefill_fp32.py 16 2048 8 8 64 > "$OUT/pmc_prefill_f32.txt"
 MLA_TARGETS=0 tools/pmc_sq.sh "$OUT/pmc_mla_mh" mla_decode_kernel_mh tools/bench_mla.py 128 128 4096 > "$OUT/pmc_mla_mh.txt"
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_mla_fetch" -o fetch -- \
   python3 tools/bench_mla.py 256 16 4096 > /dev/null 2> "$OUT/pmc_mla_fetch.log"
@@ -49,24 +43,33 @@ step secondary benchmarks
   timeout -k 10 200 python3 tools/bench_sampler.py 256 128256
   timeout -k 10 200 python3 tools/bench_gqa.py
   timeout -k 10 200 python3 tools/bench_locality.py
-  timeout -k 10 200 python3 tools/tune_decode.py c2 256
+  timeout -k 10 200 python3 tools/tune_c2.py c2
+  timeout -k 10 200 python3 tools/tune_c2.py metric
+  timeout -k 10 200 python3 tools/bench_argmax.py
+  timeout -k 10 200 python3 tools/bench_argmax.py 256 1000
   for a in "64 16 4096" "256 16 4096" "128 16 8192" "64 32 4096" "32 64 4096" "128 128 4096"; do MLA_TARGETS=0,0 timeout -k 10 120 python3 tools/bench_mla.py $a | tail -1; done
   MI355_MLA_MANY_HEADS=0 MLA_TARGETS=0 timeout -k 10 120 python3 tools/bench_mla.py 128 128 4096 | tail -1 | sed 's/^/16 heads per workgroup: /'
   timeout -k 10 200 python3 tools/bench_small_batch.py
   for a in "16 2048 8 8 64" "2 16384 8 8 64" "16 2048 32 8 128" "4 8192 32 8 128" "64 512 32 8 128"; do BENCH_MFMA_ONLY=1 timeout -k 10 120 python3 tools/bench_prefill.py $a; done
   timeout -k 10 120 python3 tools/bench_prefill_fp32.py 16 2048 8 8 64
   timeout -k 10 120 python3 tools/bench_prefill_fp32.py 16 2048 4 4 32
+  timeout -k 10 120 python3 tools/bench_prefill_fp32.py 4 8192 8 8 64
+  timeout -k 10 120 python3 tools/bench_prefill_fp32.py 16 2048 8 2 128
+  timeout -k 10 120 python3 tools/bench_paged_prefill.py 8 1024 3072 8 8 64 float32
+  MLA_TARGETS=0 timeout -k 10 120 python3 tools/bench_mla.py 256 16 4096 float32 | tail -1
   for a in "8 1024 3072 32 8 128" "8 1024 3072 8 8 64" "32 256 256 8 8 64" "64 64 1024 8 8 64"; do timeout -k 10 120 python3 tools/bench_paged_prefill.py $a; done
   timeout -k 10 200 python3 tools/bench_dtypes.py
   timeout -k 10 200 python3 tools/bench_engine.py 256 512 32
   timeout -k 10 200 python3 tools/bench_engine.py 128 256 64
   timeout -k 10 200 python3 tools/bench_engine.py 8 4096 8 1024
   timeout -k 10 200 python3 tools/bench_engine_mixed.py 512 128 2048
+  timeout -k 10 200 python3 tools/time_mixed_steps.py 512 128 2048
+  timeout -k 10 200 python3 tools/bench_reference_engine_config.py
   export MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0
-  echo "one-rank RCCL communicator (BENCH_FORCE_DIST=1): gather every 4 steps, every step, native every step, none"
+  echo "one-rank RCCL communicator (BENCH_FORCE_DIST=1): gather every step (default), every 4 steps, native every step, none"
   BENCH_FORCE_DIST=1 timeout -k 10 200 python3 bench.py --no-cpu-baseline | cut -c1-200
-  BENCH_FORCE_DIST=1 timeout -k 10 200 python3 bench.py --no-cpu-baseline --gather-every 1 | cut -c1-200
-  BENCH_FORCE_DIST=1 BENCH_NATIVE_RCCL=1 timeout -k 10 200 python3 bench.py --no-cpu-baseline --gather-every 1 | cut -c1-200
+  BENCH_FORCE_DIST=1 timeout -k 10 200 python3 bench.py --no-cpu-baseline --gather-every 4 | cut -c1-200
+  BENCH_FORCE_DIST=1 BENCH_NATIVE_RCCL=1 timeout -k 10 200 python3 bench.py --no-cpu-baseline | cut -c1-200
   timeout -k 10 200 python3 bench.py --no-cpu-baseline | cut -c1-200
 } > "$OUT/secondary.txt" 2> "$OUT/secondary.err"
 find "$OUT" -name '*.csv' | head -40 >&2

@@ -19,21 +19,13 @@ def put(rel, name):
     shutil.copyfile(os.path.join(src, rel), os.path.join(dst, f'{tag}_{name}'))
 
 
-for rel, name in [('bench_line.json', 'bench_line.json'), ('bench_line_c2.json', 'bench_line_c2.json'),
-                  ('bench_line_under_rocprof.json', 'bench_line_under_rocprof.json'),
-                  ('secondary.txt', 'secondary_benchmarks.txt'),
-                  ('pmc_fetch/fetch_counter_collection.csv', 'pmc_fetch_size.csv'),
-                  ('pmc_write/write_counter_collection.csv', 'pmc_write_size.csv'),
+subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'publish_headline.py'), tag])
+for rel, name in [('secondary.txt', 'secondary_benchmarks.txt'),
                   ('pmc_mla_fetch/fetch_counter_collection.csv', 'pmc_mla_fetch_size.csv')]:
     put(rel, name)
-for name in ('bench', 'c2', 'gqa', 'mla', 'prefill', 'engine'):
+for name in ('gqa', 'mla', 'prefill', 'engine', 'prefill_f32', 'c2tune'):
     put(f'trace_{name}/{name}_kernel_stats.csv', f'{name}_kernel_stats.csv')
 put('trace_paged_prefill/pp_kernel_stats.csv', 'paged_prefill_kernel_stats.csv')
-
-subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'pmc_traffic.py'),
-                       os.path.join(src, 'pmc_fetch/fetch_counter_collection.csv'),
-                       os.path.join(src, 'pmc_write/write_counter_collection.csv'),
-                       os.path.join(dst, f'{tag}_pmc_traffic.json')])
 
 
 def counters(path, kernel):
@@ -75,6 +67,19 @@ for shape, label in (('d128', '4 sequences x 8192 tokens, 32/8 heads, D=128, bf1
                    round(c['SQ_LDS_BANK_CONFLICT'] / c['SQ_LDS_IDX_ACTIVE'], 4),
                "waves_per_simd (4 x SQ_WAVE_CYCLES / SIMD cycles)": round(4 * c['SQ_WAVE_CYCLES'] / simd_cycles, 2)},
               open(os.path.join(dst, f'{tag}_pmc_prefill_{shape}.json'), 'w'), indent=1)
+c, n = counters(os.path.join(src, 'pmc_prefill_f32/*/*counter_collection.csv'), 'prefill_mfma_f32')
+if c:
+    cycles = c['GRBM_GUI_ACTIVE'] / 8
+    json.dump({"kernel": "prefill_mfma_f32_kernel<64, false>",
+               "workload": "16 sequences x 2048 tokens, 8 heads, D=64, fp32 (tools/bench_prefill_fp32.py 16 2048 8 8 64)",
+               "launches": n, "counters (average per launch)": {k: round(v) for k, v in sorted(c.items())},
+               "kernel_cycles (GRBM_GUI_ACTIVE summed over 8 XCDs / 8)": round(cycles),
+               "mfma_busy_fraction (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles))":
+                   round(c['SQ_VALU_MFMA_BUSY_CYCLES'] / (cycles * 1024), 4),
+               "lds_busy_fraction": round(c['SQ_LDS_IDX_ACTIVE'] / (256 * cycles), 4),
+               "lds_conflict_fraction": round(c['SQ_LDS_BANK_CONFLICT'] / c['SQ_LDS_IDX_ACTIVE'], 4),
+               "waves_per_simd (4 x SQ_WAVE_CYCLES / SIMD cycles)": round(4 * c['SQ_WAVE_CYCLES'] / (cycles * 1024), 2)},
+              open(os.path.join(dst, f'{tag}_pmc_prefill_f32.json'), 'w'), indent=1)
 c, n = counters(os.path.join(src, 'pmc_mla_mh/*/*counter_collection.csv'), 'mla_decode_kernel_mh')
 if c:
     cycles = c['GRBM_GUI_ACTIVE'] / 8

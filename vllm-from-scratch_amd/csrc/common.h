@@ -61,7 +61,11 @@ int mla_f32_launch(float* out, const float* q, int64_t q_stride_row, const float
                    int64_t ckv_stride_tok, const float* k_rope, int64_t krope_stride_seq, int64_t krope_stride_tok,
                    const float* cos_table, const float* sin_table, int table_len, const int32_t* context_lens,
                    const int32_t* row_seq, int rows, int H, int R, int P, int max_context, float scale,
-                   hipStream_t stream);
+                   void* workspace, size_t workspace_bytes, hipStream_t stream);
+void mla_f32_plan(int rows, int H, int max_context, int* nsplit, int* tps, size_t* ws_bytes, int R);
+// Combines token-split partials [rows, H, nsplit, R] + (max, sum) records into out (mla_decode.hip).
+int mla_merge_launch(float* out, float* ws_acc, float* ws_ml, const int32_t* ctx, int rows, int H, int R,
+                     int max_ctx, int nsplit, int tps, hipStream_t stream);
 
 // fp32 causal prefill on the matrix cores (prefill_mfma_f32.hip): head_dim 32 / 64 / 128, packed and paged.
 bool prefill_mfma_f32_supported(int dtype, int D);

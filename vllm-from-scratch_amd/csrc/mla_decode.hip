@@ -837,13 +837,45 @@ int launch_t(int R, const MlaParams& p, bool many, hipStream_t s) {
 }
 
 }  // namespace
+
+int mla_merge_launch(float* out, float* ws_acc, float* ws_ml, const int32_t* ctx, int rows, int H, int R,
+                     int max_ctx, int nsplit, int tps, hipStream_t stream) {
+  MlaParams p = {};
+  p.out = out;
+  p.ws_acc = ws_acc;
+  p.ws_ml = ws_ml;
+  p.ctx = ctx;
+  p.rows = rows;
+  p.H = H;
+  p.max_ctx = max_ctx;
+  p.nsplit = nsplit;
+  p.tps = tps;
+  const int64_t threads = (int64_t)rows * H * (R / 4);
+  const dim3 grid((unsigned)ceil_div64(threads, 256));
+  switch (R) {
+    case 32: hipLaunchKernelGGL((mla_merge_kernel<32>), grid, dim3(256), 0, stream, p); break;
+    case 64: hipLaunchKernelGGL((mla_merge_kernel<64>), grid, dim3(256), 0, stream, p); break;
+    case 128: hipLaunchKernelGGL((mla_merge_kernel<128>), grid, dim3(256), 0, stream, p); break;
+    case 256: hipLaunchKernelGGL((mla_merge_kernel<256>), grid, dim3(256), 0, stream, p); break;
+    case 512: hipLaunchKernelGGL((mla_merge_kernel<512>), grid, dim3(256), 0, stream, p); break;
+    default: return fail(MI355_EUNSUPPORTED, "mla merge: kv_lora_rank %d", R);
+  }
+  return check_launch("mla_merge_kernel");
+}
+
 }  // namespace mi355
 
 using namespace mi355;
 
 extern "C" size_t mi355_mla_decode_workspace_bytes(int32_t rows, int32_t H, int32_t R, int32_t P,
                                                    int32_t max_context, int32_t dtype) {
-  if (dtype == MI355_F32) return 0;   // the fp32 kernel walks a row's context in one workgroup: no partials
+  if (dtype == MI355_F32) {
+    int nsplit, tps;
+    size_t need = 0;
+    if (rows <= 0 || H <= 0 || !mla_f32_supported(R, P)) return 0;
+    mla_f32_plan(rows, H, max_context, &nsplit, &tps, &need, R);
+    return need;
+  }
   MlaPlan pl;
   if (mla_plan(rows, H, R, P, max_context, dtype, &pl)) return 0;
   return pl.ws_bytes;
@@ -872,7 +904,7 @@ extern "C" int mi355_mla_decode(float* out, const void* q, int64_t q_stride_row,
     return mla_f32_launch(out, static_cast<const float*>(q), q_stride_row, static_cast<const float*>(c_kv),
                           ckv_stride_seq, ckv_stride_tok, static_cast<const float*>(k_rope), krope_stride_seq,
                           krope_stride_tok, cos_table, sin_table, table_len, context_lens, row_seq, rows, H, R, P,
-                          max_context, scale, static_cast<hipStream_t>(stream));
+                          max_context, scale, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
   }
   MlaPlan pl;
   if (int rc = mla_plan(rows, H, R, P, max_context, dtype, &pl)) return rc;

@@ -19,8 +19,10 @@
 // that contracts tokens {r, 4 + r, 8 + r, 12 + r}.  The A operand of that product is the wave's
 // quarter tile transposed, read back from a wave-private LDS image (row pitch R/4 + 4 words: the
 // four token rows a read touches land on four disjoint groups of 16 banks).
-// No token splits: one workgroup walks a row's whole context (the 16-bit kernels serve the
-// shapes where that matters).
+// A workgroup's walk over its tokens is one dependent chain (loads -> scores -> exchange ->
+// softmax -> value product), so the chip is filled by running several workgroups per CU: when
+// rows x head tiles leave CUs idle the context is cut into token splits whose fp32 partials are
+// combined by the merge kernel of the 16-bit path (same record format).
 #include "common.h"
 
 namespace mi355 {
@@ -38,7 +40,9 @@ struct MlaF32Params {
   const int32_t* ctx;
   const int32_t* row_seq;
   int64_t q_stride_row, ckv_stride_seq, ckv_stride_tok, krope_stride_seq, krope_stride_tok;
-  int rows, H, n_ht, table_len, max_ctx;
+  int rows, H, n_ht, table_len, max_ctx, nsplit, tps;
+  float* ws_acc;   // [rows, H, nsplit, R] un-normalised partial outputs (nsplit > 1)
+  float* ws_ml;    // [rows, H, nsplit, 2] (running maximum in log2 units, sum)
   float scale_log2e;
 };
 
@@ -59,9 +63,15 @@ __global__ void __launch_bounds__(WAVES * 64) mla_decode_f32_kernel(const MlaF32
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
-  const int ht = blockIdx.x % p.n_ht, row = blockIdx.x / p.n_ht;
+  int bid = blockIdx.x;
+  const int ht = bid % p.n_ht;
+  bid /= p.n_ht;
+  const int sp = bid % p.nsplit, row = bid / p.nsplit;
   const int seq = p.row_seq ? p.row_seq[row] : row;
-  const int ctx = max(0, min(p.ctx[row], p.max_ctx));
+  const int ctx_all = max(0, min(p.ctx[row], p.max_ctx));
+  const int tok0 = sp * p.tps;                             // this split's tokens: [tok0, ctx)
+  if (p.nsplit > 1 && tok0 >= ctx_all) return;             // the merge skips splits past the context
+  const int ctx = min(ctx_all, tok0 + p.tps);
   const int head = ht * 16 + c, head_c = min(head, p.H - 1);
 
   // rope dims of this wave: step s, slot g -> index 4 s + g into [lo dims | hi dims]
@@ -97,7 +107,7 @@ __global__ void __launch_bounds__(WAVES * 64) mla_decode_f32_kernel(const MlaF32
   f32x4v kk[NJ], kk_n[NJ];
   float rv[RS], rp[RS], rc[RS], rn[RS], rv_n[RS], rp_n[RS], rc_n[RS], rn_n[RS];
   auto load_tile = [&](int t0, f32x4v (&k4)[NJ], float (&v)[RS], float (&pv)[RS], float (&cs)[RS], float (&sn)[RS]) {
-    const int key = min(t0 + c, max(ctx - 1, 0));
+    const int key = min(t0 + c, max(ctx - 1, 0));           // (t0 counts from token 0 of the sequence)
     const float* krow = ckv_seq + (int64_t)key * p.ckv_stride_tok;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) k4[j] = *reinterpret_cast<const f32x4v*>(krow + 16 * j + 4 * g);
@@ -112,11 +122,11 @@ __global__ void __launch_bounds__(WAVES * 64) mla_decode_f32_kernel(const MlaF32
     }
   };
 
-  const int ntiles = (ctx + 15) / 16;
-  if (ntiles > 0) load_tile(0, kk, rv, rp, rc, rn);
+  const int ntiles = ctx > tok0 ? (ctx - tok0 + 15) / 16 : 0;
+  if (ntiles > 0) load_tile(tok0, kk, rv, rp, rc, rn);
   float* my_v = s_v[wave];
   for (int t = 0; t < ntiles; ++t) {
-    const int t0 = t * 16;
+    const int t0 = tok0 + t * 16;
     if (t + 1 < ntiles) load_tile(t0 + 16, kk_n, rv_n, rp_n, rc_n, rn_n);
     // ---- this wave's share of the scores: 16 tokens x 16 heads over its latent quarter and rope dims
     f32x4v sp = {0.f, 0.f, 0.f, 0.f};
@@ -179,17 +189,28 @@ __global__ void __launch_bounds__(WAVES * 64) mla_decode_f32_kernel(const MlaF32
   }
 
   if (head < p.H) {
-    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
-    float* dst = p.out + ((int64_t)row * p.H + head) * R + Q * wave;
+    if (p.nsplit == 1) {
+      const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+      float* dst = p.out + ((int64_t)row * p.H + head) * R + Q * wave;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
-      *reinterpret_cast<f32x4v*>(dst + 16 * j + 4 * g) = o[j] * inv;   // rows (dims) 16 j + 4 g + r of head c
+      for (int j = 0; j < NJ; ++j)
+        *reinterpret_cast<f32x4v*>(dst + 16 * j + 4 * g) = o[j] * inv;   // rows (dims) 16 j + 4 g + r of head c
+    } else {
+      const int64_t rec = ((int64_t)row * p.H + head) * p.nsplit + sp;
+      float* dst = p.ws_acc + rec * R + Q * wave;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x4v*>(dst + 16 * j + 4 * g) = o[j];
+      if (wave == 0 && g == 0) {
+        p.ws_ml[rec * 2] = m_run;
+        p.ws_ml[rec * 2 + 1] = l_run;
+      }
+    }
   }
 }
 
 template <int R>
 int launch_r(const MlaF32Params& p, int P, hipStream_t s) {
-  const int64_t grid = (int64_t)p.rows * p.n_ht;
+  const int64_t grid = (int64_t)p.rows * p.nsplit * p.n_ht;
   if (grid >= (1LL << 31)) return fail(MI355_EINVAL, "mla_decode (fp32): grid too large");
   const dim3 g((unsigned)grid);
   if constexpr (R >= 256) {
@@ -203,10 +224,26 @@ int launch_r(const MlaF32Params& p, int P, hipStream_t s) {
       default: hipLaunchKernelGGL((mla_decode_f32_kernel<R, 64, 1>), g, dim3(64), 0, s, p); break;
     }
   }
-  return check_launch("mla_decode_f32_kernel");
+  if (int rc = check_launch("mla_decode_f32_kernel")) return rc;
+  if (p.nsplit > 1)
+    return mla_merge_launch(p.out, p.ws_acc, p.ws_ml, p.ctx, p.rows, p.H, R, p.max_ctx, p.nsplit, p.tps, s);
+  return 0;
 }
 
 }  // namespace
+
+// Token splits of the fp32 kernel: aim for two workgroups per CU, at least 256 tokens per split.
+void mla_f32_plan(int rows, int H, int max_context, int* nsplit, int* tps, size_t* ws_bytes, int R) {
+  const int64_t base = (int64_t)rows * ((H + 15) / 16);
+  const int ctx = max_context > 0 ? max_context : 1;
+  int64_t want = ceil_div64(512, base > 0 ? base : 1);
+  const int64_t most = ctx / 256 > 0 ? ctx / 256 : 1;
+  if (want > most) want = most;
+  if (want < 1) want = 1;
+  *tps = (int)(ceil_div64(ceil_div64(ctx, want), 16) * 16);
+  *nsplit = (int)ceil_div64(ctx, *tps);
+  *ws_bytes = *nsplit > 1 ? (size_t)rows * H * *nsplit * (R + 2) * sizeof(float) : 0;
+}
 
 // kv_lora_rank 32 / 64 / 128 with rope dim 8 / 16 / 32 / 64 (one wave), 256 / 512 with 32 / 64 (four waves)
 bool mla_f32_supported(int R, int P) {
@@ -218,8 +255,15 @@ int mla_f32_launch(float* out, const float* q, int64_t q_stride_row, const float
                    int64_t ckv_stride_tok, const float* k_rope, int64_t krope_stride_seq, int64_t krope_stride_tok,
                    const float* cos_table, const float* sin_table, int table_len, const int32_t* context_lens,
                    const int32_t* row_seq, int rows, int H, int R, int P, int max_context, float scale,
-                   hipStream_t stream) {
+                   void* workspace, size_t workspace_bytes, hipStream_t stream) {
   MlaF32Params p;
+  size_t need = 0;
+  mla_f32_plan(rows, H, max_context, &p.nsplit, &p.tps, &need, R);
+  if (need && (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)))
+    return fail(MI355_EWORKSPACE, "mla_decode (fp32): need %zu workspace bytes (16-B aligned), got %zu", need,
+                workspace ? workspace_bytes : (size_t)0);
+  p.ws_acc = static_cast<float*>(workspace);
+  p.ws_ml = p.ws_acc ? p.ws_acc + (size_t)rows * H * p.nsplit * R : nullptr;
   p.out = out;
   p.q = q;
   p.ckv = c_kv;
