@@ -1,6 +1,6 @@
 """Two-rank data-parallel engine run on one GPU (launched by tests/conftest.py under
 torch.distributed.run before the test session touches the device; checked by
-tests/test_dropin_gpu_dp.py).  Backend gloo: the ranks share the one GPU and the sampled ids
+tests/test_zy_dp_engine_gpu.py).  Backend gloo: the ranks share the one GPU and the sampled ids
 travel through host memory; the control flow is the one the RCCL run uses.
 
     python -m torch.distributed.run --nproc-per-node 2 ... tests/dp_engine_job.py <out_dir>

@@ -21,8 +21,9 @@ eng = mv.MiniVLLM(vocab_size=32000, hidden_size=512, num_layers=4, num_heads=8, 
                   num_kv_blocks=nseq * 40, block_size=16, max_num_seqs=nseq, max_num_batched_tokens=budget,
                   device='cuda', dtype=torch.bfloat16)
 
-for rep in range(2):                       # one engine serves both passes: the first warms kernels,
-    for p, n in zip(plens, news):          # GEMM plans and the captured decode graphs, the second is timed
+PASSES = int(os.environ.get('ENGINE_PASSES', '3'))
+for rep in range(PASSES):                  # one engine serves all passes (fresh random prompts each): the first warms
+    for p, n in zip(plens, news):          # kernels, GEMM plans and captures most step shapes, the later ones are timed
         eng.add_request([int(t) for t in rng.integers(1, 32000, size=int(p))], max_new_tokens=int(n), temperature=0.0)
     steps = fast = 0
     out_tokens = 0
@@ -35,6 +36,9 @@ for rep in range(2):                       # one engine serves both passes: the 
         steps += 1
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-print(f"{nreq} requests (prompts U[64,512], {int(plens.sum())} prompt tokens; {out_tokens} generated), {nseq} slots, "
+    if rep == 0:
+        continue
+    print(f"pass {rep + 1}: {len(eng._graphs)} captured decode shapes, {len(eng._mixed)} captured prompt-step shapes; ", end='')
+    print(f"{nreq} requests (prompts U[64,512], {int(plens.sum())} prompt tokens; {out_tokens} generated), {nseq} slots, "
       f"budget {budget}: {dt * 1e3:.1f} ms, {steps} steps ({fast} captured decode launches), "
-      f"{(int(plens.sum()) + out_tokens) / dt:.0f} tokens/s total, {out_tokens / dt:.0f} generated tokens/s")
+          f"{(int(plens.sum()) + out_tokens) / dt:.0f} tokens/s total, {out_tokens / dt:.0f} generated tokens/s", flush=True)

@@ -259,9 +259,27 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
   constexpr int kTieCap = 64;
   __shared__ int s_tie_i[kTieCap];
   __shared__ int s_tie_n;
+  __shared__ float s_walk[VPT > 0 ? VPT : 1];   // the picking thread's elements, handed to wave 0
+  __shared__ float s_walk_base;
   int slot = 0;
   const int tid = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
+  // Wave 0 finds the first of the picker's elements (s_walk, running sum starting at s_walk_base)
+  // whose running sum passes the target, with a prefix scan, and writes its index.
+  auto walk_pick = [&](int picker, float target) {
+    const float q = lane < VPT ? s_walk[lane < VPT ? lane : 0] : 0.f;
+    float run = q;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const float o = __shfl_up(run, off);
+      if (lane >= off) run += o;
+    }
+    run += s_walk_base;
+    const unsigned long long hit = __ballot(q > 0.f && run > target);
+    const unsigned long long any = __ballot(q > 0.f);          // not empty: the picker's mass is > 0
+    const int j = hit ? __ffsll((long long)hit) - 1 : 63 - __clzll((long long)any);
+    if (lane == 0) p.out[b] = VEC ? ((j / EPL) * nt + picker) * EPL + (j % EPL) : j * nt + picker;
+  };
   const typename Tag::elem_t* row = static_cast<const typename Tag::elem_t*>(p.logits) + (int64_t)b * p.row_stride;
   const int vocab = p.vocab;
   const float temp = p.temperature[b];
@@ -343,6 +361,56 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
       mx = fmaxf(mx, pr[j]);
     }
     mx = block_reduce(mx, fmaxop, xch, slot);
+    // A row without a cut whose distribution nobody asked for only needs its draw: weights
+    // e = exp2((x/T - max) log2 e) (a plain exp2: the extra digits of exp_nonpos pin the kept set of
+    // a cut, here they would only move a draw by an ulp of the target), no division by their sum --
+    // the target is scaled instead -- and the sum itself falls out of the scan over threads.
+    if (!(tp < 1.0f || tk > 0) && !p.out_probs) {
+      float mine = 0.f;
+#pragma unroll
+      for (int j = 0; j < VPT; ++j) {
+        pr[j] = __builtin_amdgcn_exp2f((pr[j] - mx) * 1.44269504088896340736f);   // absent elements: 0
+        mine += pr[j];
+      }
+      float incl = mine;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const float o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+      }
+      if (lane == 63) s_scan[wave] = incl;
+      if (tid == 0) s_pick = 0x7fffffff;
+      __syncthreads();
+      float base = 0.f, total = 0.f;
+      const int nw = nt >> 6;
+#pragma unroll
+      for (int w = 0; w < kMaxWaves; ++w) {
+        const float v = w < nw ? s_scan[w] : 0.f;
+        total += v;
+        base += w < wave ? v : 0.f;
+      }
+      const float target = philox_uniform(p.seed, p.offset + (uint64_t)b) * total;
+      const float excl = base + incl - mine;
+      if (mine > 0.f && excl <= target && target < excl + mine) atomicMin(&s_pick, tid);
+      __syncthreads();
+      const int picker = s_pick;
+      if (picker == 0x7fffffff) {      // rounding pushed the target past the walked total: the last weighted element
+        int last = -1;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) last = (pr[j] > 0.f && eidx(j) < vocab) ? max(last, eidx(j)) : last;
+        last = block_reduce(last, maxi, xch, slot);
+        if (tid == 0) p.out[b] = max(last, 0);
+        return;
+      }
+      if (tid == picker) {
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) s_walk[j] = eidx(j) < vocab ? pr[j] : 0.f;
+        s_walk_base = excl;
+      }
+      __syncthreads();
+      if (wave == 0) walk_pick(picker, target);
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
       pr[j] = exp_nonpos(pr[j] - mx);    // absent elements: exp(-inf) = 0
@@ -551,28 +619,13 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
     // The picking thread's elements go through LDS to the lanes of wave 0, which finds the first one
     // whose running sum passes the target with a prefix scan (one thread walking its 32 registers
     // alone costs more than the rest of the draw).
-    __shared__ float s_walk[VPT];
-    __shared__ float s_walk_base;
     if (tid == picker) {
 #pragma unroll
       for (int j = 0; j < VPT; ++j) s_walk[j] = (pr[j] >= 0.f && is_kept(pr[j], eidx(j))) ? pr[j] : 0.f;
       s_walk_base = excl;
     }
     __syncthreads();
-    if (wave == 0) {
-      const float q = lane < VPT ? s_walk[lane] : 0.f;
-      float run = q;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const float o = __shfl_up(run, off);
-        if (lane >= off) run += o;
-      }
-      run += s_walk_base;
-      const unsigned long long hit = __ballot(q > 0.f && run > target);
-      const unsigned long long any = __ballot(q > 0.f);          // not empty: the picker's mass is > 0
-      const int j = hit ? __ffsll((long long)hit) - 1 : 63 - __clzll((long long)any);
-      if (lane == 0) p.out[b] = VEC ? ((j / EPL) * nt + picker) * EPL + (j % EPL) : j * nt + picker;
-    }
+    if (wave == 0) walk_pick(picker, target);
   } else {
     if (tid == picker) {
       float run = excl;

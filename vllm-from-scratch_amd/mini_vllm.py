@@ -1026,8 +1026,7 @@ class MixedStep:
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side), torch.no_grad():      # warm-up: workspaces, GEMM plans
-                for _ in range(2):
-                    self._body()
+                self._body()
             torch.cuda.current_stream(dev).wait_stream(side)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph), torch.no_grad():
@@ -1187,7 +1186,7 @@ class MiniVLLM:
     def _mixed_step(self, tokens: int, nreq: int, max_q: int, max_ctx: int) -> MixedStep:
         """The (captured) step serving `tokens` token rows of `nreq` requests with prompt chunks up
         to `max_q` tokens and contexts up to `max_ctx`, at the padded sizes of its bucket."""
-        S = _bucket_pow(nreq, 2, 8)
+        S = _bucket_pow(nreq, 4, 8)           # 8, 32, 128, ...: few slot counts, so few distinct graphs
         T = max(_bucket_tokens(tokens), S)
         Q = min(_bucket_pow(max(max_q, 1), 4, 16), T)
         C = _bucket_pow(max_ctx, 2, 256)
