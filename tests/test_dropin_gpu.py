@@ -466,3 +466,49 @@ def test_engine_bf16_chunked_prefill_uses_paged_prefill_kernel(mv, device, monke
     torch.testing.assert_close(logits['whole'], logits['fp32'], atol=0.08, rtol=0.05)
     torch.testing.assert_close(logits['chunked'], logits['fp32'], atol=0.08, rtol=0.05)
     torch.testing.assert_close(logits['chunked'], logits['whole'], atol=0.08, rtol=0.05)
+
+
+# ------------------------------------------------------------------ bucketed (captured) steps vs the planned eager path
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 2e-4), (torch.bfloat16, 6e-2)])
+def test_engine_bucketed_steps_match_the_planned_path(mv, device, dtype, tol):
+    """Steps with prompt chunks run at padded sizes through MixedStep (all chunks in one
+    paged-prefill launch, decode rows first); the planned path (build_attn_plan: first chunks on
+    the packed prompt kernel, exact launch sizes) is an independent implementation of the same
+    step.  Same weights, same requests, chunked prompts mixed with decode tokens and arrivals
+    mid-run: every step's logits agree within GEMM / attention rounding and, in fp32, every
+    request gets the same tokens."""
+    kw = dict(vocab_size=300, hidden_size=128, num_layers=2, num_heads=4, intermediate_size=256,
+              num_kv_blocks=200, block_size=8, max_num_seqs=6, max_num_batched_tokens=48, device='cuda',
+              dtype=dtype, decode_graphs=False)
+    rng = np.random.default_rng(17)
+    prompts = [[int(t) for t in rng.integers(1, 300, size=int(n))] for n in (5, 70, 1, 33, 120, 9, 48, 17, 2, 90)]
+
+    def run(mixed):
+        torch.manual_seed(3)
+        eng = mv.MiniVLLM(**kw)
+        eng.mixed_steps = mixed
+        ids = [eng.add_request(p, max_new_tokens=7, temperature=0.0) for p in prompts[:6]]
+        outs, logs, steps = {r: [] for r in ids}, [], 0
+        while eng.scheduler.has_unfinished:
+            if steps == 5:
+                for p in prompts[6:]:
+                    outs[eng.add_request(p, max_new_tokens=5, temperature=0.0)] = []
+            for rid, tok in eng.step():
+                outs[rid].append(tok)
+            logs.append(eng.last_logits.float().cpu())
+            steps += 1
+        assert eng.allocator.num_free == 200
+        return eng, outs, logs
+
+    bucketed, out_b, log_b = run(True)
+    planned, out_p, log_p = run(False)
+    assert len(bucketed._mixed) >= 2 and not planned._mixed            # both paths were really taken
+    if dtype == torch.float32:
+        assert out_b == out_p
+        assert len(log_b) == len(log_p)
+        for a, b in zip(log_b, log_p):
+            torch.testing.assert_close(a, b, atol=tol, rtol=1e-3)
+    else:
+        # bf16: a near-tie may resolve differently and the runs then diverge; the first steps (same inputs) must agree
+        for a, b in list(zip(log_b, log_p))[:3]:
+            torch.testing.assert_close(a, b, atol=tol, rtol=5e-2)
