@@ -1,5 +1,6 @@
 """Host-side planning of the engine (CPU only): which kernel serves which token of a flattened
 step, and the persistent device block-table mirror (exercised here on torch's CPU device)."""
+import pytest
 import torch
 
 from mini_vllm import DeviceBlockTables, Request, build_attn_plan
@@ -287,3 +288,92 @@ def test_paged_prefill_serves_rule():
     assert not ops.paged_prefill_serves(torch.bfloat16, 64, 16, 47, limit + 1)      # short chunk: append kernel, staged
     assert ops.paged_prefill_serves(torch.bfloat16, 64, 16, 48, 10 * limit)         # flash kernel reads the table itself
     assert not ops.paged_prefill_serves(torch.bfloat16, 48, 16, 48, 100)            # head_dim without a kernel
+
+
+# --- update() split in two halves, for an engine that issues step i + 1 before reading step i's ids
+
+def _token_rule(req, k):
+    """Token k of a request: depends on the request and k only, 0 (end of sequence) now and then."""
+    return (int(req.request_id.split('-')[1]) * 7 + k * 5 + 3) % 11
+
+
+def _split_sched(seed, chunked, prefix=False):
+    from mini_vllm import BlockAllocator, Scheduler
+    import random
+    rng = random.Random(seed)
+    alloc = BlockAllocator(num_blocks=96, block_size=4)
+    sched = Scheduler(max_num_seqs=5, max_num_batched_tokens=24, block_size=4, allocator=alloc,
+                      enable_chunked_prefill=chunked, enable_prefix_caching=prefix)
+    for i in range(20):
+        plen = rng.randint(1, 22)
+        prompt = [1 + (i % 3)] * plen if prefix else [rng.randint(1, 50) for _ in range(plen)]
+        sched.add_request(Request(request_id=f'req-{i}', prompt_token_ids=prompt, max_new_tokens=rng.randint(1, 9)))
+    return sched, alloc
+
+
+def _trace_item(item):
+    return (item.request.request_id, item.start, len(item.tokens), item.is_prefill, tuple(item.request.block_table))
+
+
+@pytest.mark.parametrize('chunked', [True, False])
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_advance_then_resolve_equals_update(seed, chunked):
+    a, alloc_a = _split_sched(seed, chunked)
+    b, alloc_b = _split_sched(seed, chunked)
+    steps = 0
+    while a.has_unfinished:
+        sa, sb = a.schedule(), b.schedule()
+        assert [_trace_item(x) for x in sa] == [_trace_item(x) for x in sb]
+        if not sa:
+            break
+        toks = [_token_rule(x.request, len(x.request.output_token_ids)) for x in sa]
+        a.update(sa, toks)
+        takes = b.advance(sb)
+        assert all(x.request.output_token_ids[-1] == -1 - j for j, x in enumerate(sb) if takes[j])
+        b.resolve(sb, takes, toks)
+        assert alloc_a.num_free == alloc_b.num_free
+        assert [r.request_id for r in a.running] == [r.request_id for r in b.running]
+        steps += 1
+    assert steps > 10 and not b.has_unfinished
+    assert ({r.request_id: r.output_token_ids for r in a.finished}
+            == {r.request_id: r.output_token_ids for r in b.finished})
+    assert any(r.output_token_ids[-1] == 0 for r in a.finished)          # ends on the end-of-sequence id happened
+    assert any(r.output_token_ids[-1] != 0 for r in a.finished)          # and so did ends by length
+
+
+@pytest.mark.parametrize('prefix', [False, True])
+@pytest.mark.parametrize('seed', [0, 1, 2, 3])
+def test_scheduling_one_step_ahead_gives_every_request_the_same_tokens(seed, prefix):
+    """The engine's pipelined loop on the scheduler alone: step i + 1 is scheduled between advance()
+    and resolve() of step i.  A request that ended on the end-of-sequence id in step i has a wasted
+    item in step i + 1; everybody's tokens equal those of the step-by-step loop."""
+    a, alloc_a = _split_sched(seed, True, prefix)
+    while a.has_unfinished:
+        sa = a.schedule()
+        if not sa:
+            break
+        a.update(sa, [_token_rule(x.request, len(x.request.output_token_ids)) for x in sa])
+    want = {r.request_id: r.output_token_ids for r in a.finished}
+
+    b, alloc_b = _split_sched(seed, True, prefix)
+    cur = b.schedule()
+    wasted = steps = 0
+    while cur:
+        wasted += sum(1 for x in cur if x.request.is_finished)
+        takes = b.advance(cur)
+        # the ids of this step, as the device would produce them (index = outputs before this step's stand-in)
+        toks = [_token_rule(x.request, len(x.request.output_token_ids) - 1) if takes[j] else -7
+                for j, x in enumerate(cur)]
+        nxt = b.schedule()
+        for x in nxt:                                   # decode items feed a stand-in or a known id, never garbage
+            if not x.is_prefill:
+                t = x.tokens[0]
+                assert t >= 0 or takes[-1 - t] and cur[-1 - t].request is x.request
+        b.resolve(cur, takes, toks)
+        cur = nxt
+        steps += 1
+    assert not b.has_unfinished and steps > 10 and wasted > 0
+    got = {r.request_id: r.output_token_ids for r in b.finished}
+    assert got == want
+    assert alloc_b.num_free == alloc_a.num_free
+    assert len(b.finished) == len(set(id(r) for r in b.finished)) == 20

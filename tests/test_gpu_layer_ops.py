@@ -328,6 +328,78 @@ def test_engine_more_requests_than_slots_equals_eager(device):
     assert ahead.allocator.num_free == 256 and plain.allocator.num_free == 256
 
 
+@pytest.mark.parametrize('prefix', [False, True])
+def test_engine_steps_with_prompt_chunks_issued_ahead_equal_eager(device, prefix):
+    """Prompts longer than the token budget (several chunks each), more requests than slots, a
+    12-id vocabulary (frequent end-of-sequence ids): steps that hold prompt chunks are issued before
+    the previous step's ids are read, decode rows feeding those ids from device memory.  Every
+    request gets the tokens the step-by-step engines give it; a request that drew the end-of-sequence
+    id costs one dropped row; blocks all return."""
+    import mini_vllm as mv
+    rng = np.random.default_rng(77)
+    prompts = [[int(t) for t in rng.integers(1, 12, size=int(n))] for n in rng.integers(3, 90, size=36)]
+    if prefix:
+        for p in prompts[::3]:
+            p[:16] = prompts[0][:16] if len(prompts[0]) >= 16 else p[:16]
+    max_new = [int(n) for n in rng.integers(2, 24, size=36)]
+
+    def run(**kw):
+        torch.manual_seed(3)
+        eng = mv.MiniVLLM(vocab_size=12, hidden_size=128, num_layers=2, num_heads=4, intermediate_size=256,
+                          num_kv_blocks=160, block_size=8, max_num_seqs=6, max_num_batched_tokens=40,
+                          device='cuda', dtype=torch.float32, enable_prefix_caching=prefix, **kw)
+        ids = [eng.add_request(p, max_new_tokens=n, temperature=0.0) for p, n in zip(prompts, max_new)]
+        outs = {rid: [] for rid in ids}
+        steps = 0
+        while eng.scheduler.has_unfinished:
+            for rid, tok in eng.step():
+                outs[rid].append(tok)
+            steps += 1
+        assert eng.allocator.num_free == 160 and eng._flight is None and eng._deferred is None
+        return eng, [outs[r] for r in ids], steps
+
+    eager, want, _ = run(decode_graphs=False)
+    assert all(len(t) >= 1 and all(0 <= x < 12 for x in t) for t in want)
+    assert sum(1 for t, n in zip(want, max_new) if t[-1] == 0 and len(t) < n) >= 5
+    stepwise, got_s, steps_s = run(pipeline_steps=False)
+    ahead, got_a, steps_a = run(pipeline_steps=True)
+    assert got_s == want and got_a == want
+    assert stepwise._ahead == 0 and ahead._ahead > 30
+    assert ahead.scheduler.dropped_items >= 1 and stepwise.scheduler.dropped_items == 0
+    assert steps_a <= steps_s + ahead.scheduler.dropped_items + 2
+
+
+def test_engine_step_scheduled_ahead_that_cannot_be_issued_ahead(device, monkeypatch):
+    """A step scheduled while its predecessor is in flight, but whose contexts the replayable body
+    does not serve (here: the staged-table limit lowered to 256 tokens), waits for the general path:
+    by then its decode items carry real ids and requests that ended meanwhile are dropped."""
+    import mini_vllm as mv
+    from mi355_paged import ops as _ops
+    monkeypatch.setattr(_ops, 'PAGED_PREFILL_STAGED_BLOCKS', 32)
+    rng = np.random.default_rng(5)
+    lens = [300, 20, 12, 330, 9, 40, 280, 15, 22, 310, 7, 18]
+    prompts = [[int(t) for t in rng.integers(1, 12, size=n)] for n in lens]
+    max_new = [int(n) for n in rng.integers(3, 20, size=len(lens))]
+
+    def run(**kw):
+        torch.manual_seed(9)
+        eng = mv.MiniVLLM(vocab_size=12, hidden_size=128, num_layers=2, num_heads=4, intermediate_size=256,
+                          num_kv_blocks=256, block_size=8, max_num_seqs=4, max_num_batched_tokens=48,
+                          device='cuda', dtype=torch.float32, **kw)
+        ids = [eng.add_request(p, max_new_tokens=n, temperature=0.0) for p, n in zip(prompts, max_new)]
+        outs = {rid: [] for rid in ids}
+        while eng.scheduler.has_unfinished:
+            for rid, tok in eng.step():
+                outs[rid].append(tok)
+        assert eng.allocator.num_free == 256 and eng._flight is None and eng._deferred is None
+        return eng, [outs[r] for r in ids]
+
+    _, want = run(decode_graphs=False)
+    eng, got = run()
+    assert got == want
+    assert eng._deferrals >= 2 and eng._ahead >= 10
+
+
 def test_engine_lookahead_accepts_requests_mid_run(device):
     """A request added while a speculative step is in flight joins through the general path and
     every request still gets the tokens it gets when run alone (greedy)."""

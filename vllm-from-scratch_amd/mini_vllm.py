@@ -237,6 +237,10 @@ class Scheduler:
         self.waiting: List[Request] = []
         self.running: List[Request] = []
         self.finished: List[Request] = []
+        # steps issued to the device whose tokens have not been handed out yet (see advance()):
+        # counted by has_unfinished, so a driver loop keeps stepping until they are returned
+        self.in_flight = 0
+        self.dropped_items = 0      # items issued for a request that had already ended (their rows are wasted)
 
     def add_request(self, request: Request):
         self.waiting.append(request)
@@ -284,42 +288,44 @@ class Scheduler:
                                 block_size=self.block_size)
 
     def schedule(self) -> List[ScheduledRequest]:
+        # The loop below runs once per request per step on the host while the device idles, so it is
+        # written flat: limits in locals, properties and helpers expanded where they are on the
+        # common path (a decode request whose table already covers its next position).
         batch: List[ScheduledRequest] = []
         budget = self.max_num_batched_tokens
         chunked = self.enable_chunked_prefill
-
-        def room() -> bool:
-            return len(batch) < self.max_num_seqs and budget >= 1
+        max_seqs, bs = self.max_num_seqs, self.block_size
 
         survivors: List[Request] = []
         for req in self.running:
             if req.is_finished:
                 continue
             survivors.append(req)
-            if req.is_prefill:
-                left = req.prompt_len - req.num_computed_tokens
+            done = req.num_computed_tokens
+            left = len(req.prompt_token_ids) - done
+            if left > 0:                                   # still in its prompt: the next chunk
                 want = min(left, budget) if chunked else left
-                if want <= 0 or not room():
+                if want <= 0 or len(batch) >= max_seqs or budget < 1:
                     continue
                 want = min(want, budget)          # a running request never exceeds the budget
                 if not self._ensure_blocks(req, want):
                     continue
-                first = req.num_computed_tokens
-                batch.append(self._emit(req, req.prompt_token_ids[first:first + want], first, True))
+                batch.append(ScheduledRequest(req, req.prompt_token_ids[done:done + want], None, True, None, done, bs))
                 budget -= want
             else:
+                if len(batch) >= max_seqs or budget < 1:
+                    continue
                 # (the table usually covers the next position already: skip the call then)
-                if not room() or (len(req.block_table) * self.block_size <= req.num_computed_tokens
-                                  and not self._ensure_blocks(req, 1)):
+                if len(req.block_table) * bs <= done and not self._ensure_blocks(req, 1):
                     continue
                 last = req.output_token_ids[-1:] or req.prompt_token_ids[-1:]
-                batch.append(self._emit(req, last, req.num_computed_tokens, False))
+                batch.append(ScheduledRequest(req, last, None, False, None, done, bs))
                 budget -= len(last)
         self.running = survivors
 
         still_waiting: List[Request] = []
         for k, req in enumerate(self.waiting):
-            if not room():                             # room() never comes back within a step:
+            if len(batch) >= max_seqs or budget < 1:   # room never comes back within a step:
                 still_waiting.extend(self.waiting[k:])  # everybody behind stays queued, in order
                 break
             if self.enable_prefix_caching and not req.block_table and req.num_computed_tokens == 0:
@@ -340,20 +346,86 @@ class Scheduler:
         """Advance every scheduled request by the tokens it was fed; a request whose prompt
         is fully consumed takes the sampled token, and finishes on max_new_tokens or on
         token id 0 (the demo's end-of-sequence id), returning its blocks."""
+        caching = self.enable_prefix_caching
+        any_finished = False
         for item, token in zip(scheduled, next_token_ids):
             req = item.request
             req.num_computed_tokens += len(item.tokens)
-            if self.enable_prefix_caching and item.is_prefill:
-                self._register_prompt_blocks(req)
-            if item.is_prefill and req.is_prefill:
-                continue                              # more prompt chunks to come
-            req.output_token_ids.append(token)
-            if len(req.output_token_ids) >= req.max_new_tokens or token == 0:
+            if item.is_prefill:
+                if caching:
+                    self._register_prompt_blocks(req)
+                if req.num_computed_tokens < len(req.prompt_token_ids):
+                    continue                              # more prompt chunks to come
+            out = req.output_token_ids
+            out.append(token)
+            if len(out) >= req.max_new_tokens or token == 0:
                 req.is_finished = True
+                free = self.allocator.free
                 for block in req.block_table:
-                    self.allocator.free(block)
-                self.running = [r for r in self.running if r is not req]
+                    free(block)
+                any_finished = True
                 self.finished.append(req)
+        if any_finished:
+            self.running = [r for r in self.running if not r.is_finished]
+
+    # update() in two halves (no counterpart in the reference), for an engine that issues step
+    # i + 1 before it has read the tokens sampled by step i.  Everything schedule() looks at --
+    # positions, prompt progress, output counts, finishing by length, free blocks -- is known
+    # without the token values; only finishing on the end-of-sequence id needs them.
+
+    def advance(self, scheduled: List[ScheduledRequest]) -> List[bool]:
+        """The half of update() that does not need the sampled ids.  Request j of the step, if it
+        takes a token, gets the stand-in -1 - j appended to its outputs (row j of the step's id
+        vector: a later step feeds it from device memory) and finishes here if that reaches
+        max_new_tokens.  Items whose request has finished meanwhile (it sampled the end-of-sequence
+        id in the step before, found out after this one was issued) are skipped.
+        Returns, per item, whether it takes a token."""
+        caching = self.enable_prefix_caching
+        takes = [False] * len(scheduled)
+        any_finished = False
+        for j, item in enumerate(scheduled):
+            req = item.request
+            if req.is_finished:
+                self.dropped_items += 1
+                continue
+            req.num_computed_tokens += len(item.tokens)
+            if item.is_prefill:
+                if caching:
+                    self._register_prompt_blocks(req)
+                if req.num_computed_tokens < len(req.prompt_token_ids):
+                    continue
+            takes[j] = True
+            out = req.output_token_ids
+            out.append(-1 - j)
+            if len(out) >= req.max_new_tokens:
+                req.is_finished = True
+                free = self.allocator.free
+                for block in req.block_table:
+                    free(block)
+                any_finished = True
+                self.finished.append(req)
+        if any_finished:
+            self.running = [r for r in self.running if not r.is_finished]
+        return takes
+
+    def resolve(self, scheduled: List[ScheduledRequest], takes: List[bool], token_ids: List[int]):
+        """The other half: the stand-ins left by advance() become the sampled ids, and a request
+        that drew the end-of-sequence id finishes now."""
+        any_finished = False
+        for item, took, token in zip(scheduled, takes, token_ids):
+            if not took:
+                continue
+            req = item.request
+            req.output_token_ids[-1] = token
+            if token == 0 and not req.is_finished:
+                req.is_finished = True
+                free = self.allocator.free
+                for block in req.block_table:
+                    free(block)
+                any_finished = True
+                self.finished.append(req)
+        if any_finished:
+            self.running = [r for r in self.running if not r.is_finished]
 
     def schedule_decode_only(self) -> Optional[List[Request]]:
         """The outcome of schedule() for the steady state of generation, without building
@@ -405,7 +477,7 @@ class Scheduler:
 
     @property
     def has_unfinished(self) -> bool:
-        return bool(self.waiting or self.running)
+        return bool(self.waiting or self.running or self.in_flight)
 
 
 # ---------------------------------------------------------------------------
@@ -1012,13 +1084,16 @@ class MixedStep:
     without graphs computes bit for bit what the captured engine computes)."""
 
     def __init__(self, model: "MiniTransformer", tables: DeviceBlockTables, tokens: int, slots: int, max_q: int,
-                 max_ctx: int, capture: bool):
+                 max_ctx: int, capture: bool, prev_ids: Optional[torch.Tensor] = None):
         dev = tables.device
         self.model, self.T, self.S, self.max_q, self.max_ctx = model, tokens, slots, max_q, max_ctx
         self.table_tensor = tables.tables
+        self.prev_ids = prev_ids                     # token entries -1-j read prev_ids[j]
         n = 3 * tokens + 7 * slots
-        self.host = torch.zeros((n,), dtype=torch.int32).pin_memory()
-        self.host_np = self.host.numpy()
+        # two staging buffers: a step may be filled in while the previous one, which read the other
+        # buffer, has not started on the device yet
+        self.host = [torch.zeros((n,), dtype=torch.int32).pin_memory() for _ in range(2)]
+        self.host_np = [h.numpy() for h in self.host]
         self.dev = torch.zeros((n,), dtype=torch.int32, device=dev)
         self.dev[tokens:2 * tokens].fill_(-1)
         self.graph = None
@@ -1037,7 +1112,7 @@ class MixedStep:
         per_token = self.dev[:3 * T].view(3, T)
         per_slot = self.dev[3 * T:].view(7, S)
         tok, pos, slots, _, _ = ops.decode_step_inputs(per_token, self.table_tensor, self.model.block_size,
-                                                       gather_tables=False)
+                                                       self.prev_ids, gather_tables=False)
         plan = AttnPlan(total_tokens=T, causal_index=None, cu_seqlens=None, causal_tokens=0, max_causal_len=0,
                         paged_index=slice(0, S), paged_tables=self.table_tensor.index_select(0, per_slot[5]),
                         paged_context=per_slot[4], paged_rows=S, max_context=self.max_ctx,
@@ -1045,9 +1120,9 @@ class MixedStep:
                         append_meta=per_slot[0:3], max_append_len=self.max_q, max_append_context=self.max_ctx)
         return self.model.forward_planned(tok, pos, slots, plan, last=per_slot[6])
 
-    def run(self, nreq: int) -> torch.Tensor:
-        """Logits [nreq, vocab] for the step described in host_np (valid until the next run)."""
-        self.dev.copy_(self.host, non_blocking=True)
+    def run(self, nreq: int, parity: int = 0) -> torch.Tensor:
+        """Logits [nreq, vocab] for the step described in host_np[parity] (valid until the next run)."""
+        self.dev.copy_(self.host[parity & 1], non_blocking=True)
         if self.graph is not None:
             self.graph.replay()
             return self.logits[:nreq]
@@ -1113,6 +1188,15 @@ class Sampler:
 # ---------------------------------------------------------------------------
 
 @dataclass
+class _Flight:
+    """A step with prompt chunks that has been issued: the scheduler's items, the pinned host vector
+    its sampled ids are being copied to, and the event that marks the copy's end."""
+    scheduled: List[ScheduledRequest]
+    ids_host: torch.Tensor
+    done: "torch.cuda.Event"
+
+
+@dataclass
 class _InflightDecode:
     """A decode step that has been issued: its requests in batch order, the pinned host vector its
     sampled ids are being copied to, and the event that marks the copy's end."""
@@ -1126,8 +1210,9 @@ class MiniVLLM:
     (05_mini_vllm/mini_vllm.py:641-783).  Extra keyword arguments, all optional:
     reference_compat (see module docstring), dtype (parameter / KV cache dtype), decode_graphs
     (replay pure-decode steps as captured HIP graphs), decode_lookahead (with decode_graphs: issue
-    the next pure-decode step before the host has read this one's tokens, see _step_decode_only)
-    and enable_prefix_caching (reuse the KV blocks of equal prompt prefixes; needs true-context
+    the next pure-decode step before the host has read this one's tokens, see _step_decode_only),
+    pipeline_steps (with decode_lookahead: the same for steps that hold prompt chunks, see
+    _step_pipelined) and enable_prefix_caching (reuse the KV blocks of equal prompt prefixes; needs true-context
     attention, so not with reference_compat)."""
 
     def __init__(self, vocab_size: int = 1000, hidden_size: int = 128, num_layers: int = 2,
@@ -1136,7 +1221,7 @@ class MiniVLLM:
                  enable_chunked_prefill: bool = True, device: str = 'cpu',
                  reference_compat: bool = False, dtype: Optional[torch.dtype] = None,
                  decode_graphs: bool = True, enable_prefix_caching: bool = False,
-                 decode_lookahead: bool = True):
+                 decode_lookahead: bool = True, pipeline_steps: bool = True):
         self.device = torch.device(device)
         self.reference_compat = reference_compat
         # replay pure-decode steps as HIP graphs (device-resident engines only)
@@ -1148,7 +1233,13 @@ class MiniVLLM:
         self._mixed: "OrderedDict[tuple, MixedStep]" = OrderedDict()
         self.decode_lookahead = decode_lookahead and self.decode_graphs
         self._inflight: Optional[_InflightDecode] = None   # a decode step issued, its tokens not read yet
-        self._launches = 0
+        self.pipeline_steps = pipeline_steps and self.decode_lookahead and self.mixed_steps
+        self._flight: Optional[_Flight] = None             # the same for a step with prompt chunks
+        self._deferred: Optional[List[ScheduledRequest]] = None   # scheduled ahead, could not be issued ahead
+        self._launches = 0                                 # captured decode steps issued
+        self._issued = 0                                   # steps issued through replayable bodies, of both kinds
+        self._deferrals = 0                                # steps scheduled ahead that had to wait for the general path
+        self._ahead = 0                                    # steps with prompt chunks issued before the previous one's ids were read
         self._ids_dev: Optional[torch.Tensor] = None       # where every captured step's sampler writes
         self._ids_host: List[torch.Tensor] = []
         self._ids_done: List[torch.cuda.Event] = []
@@ -1191,22 +1282,25 @@ class MiniVLLM:
         Q = min(_bucket_pow(max(max_q, 1), 4, 16), T)
         C = _bucket_pow(max_ctx, 2, 256)
         tables = self._device_tables
-        key = (T, S, Q, C, tables.tables.data_ptr(), tables.tables.shape[1], self.model.weights_version())
+        key = (T, S, Q, C, tables.tables.data_ptr(), tables.tables.shape[1], self.model.weights_version(),
+               self._ids_dev.data_ptr())
         step = self._mixed.get(key)
         if step is None:
             for stale in [k for k in self._mixed if k[4:] != key[4:]]:
                 del self._mixed[stale]           # block tables, KV buffers or weights were replaced
             while len(self._mixed) >= self.MAX_MIXED:
                 self._mixed.popitem(last=False)
-            step = self._mixed[key] = MixedStep(self.model, tables, T, S, Q, C, capture=self.decode_graphs)
+            step = self._mixed[key] = MixedStep(self.model, tables, T, S, Q, C, capture=self.decode_graphs,
+                                                prev_ids=self._ids_dev)
         else:
             self._mixed.move_to_end(key)
         return step
 
-    def _run_mixed(self, scheduled: List[ScheduledRequest], rows: List[int]) -> Optional[torch.Tensor]:
+    def _run_mixed(self, scheduled: List[ScheduledRequest], rows: List[int], parity: int = 0) -> Optional[torch.Tensor]:
         """Logits [len(scheduled), vocab], in scheduled order, of a step through MixedStep; None when
         the step's contexts are beyond what the paged-prefill kernels serve for this chunk length
-        (the general path then splits such contexts over paged-decode rows)."""
+        (the general path then splits such contexts over paged-decode rows).  A decode token
+        -1 - j stands for entry j of the ids the previous step sampled (read on the device)."""
         decode = [i for i, item in enumerate(scheduled) if not item.is_prefill and len(item.tokens) == 1]
         is_decode = set(decode)
         chunks = [i for i in range(len(scheduled)) if i not in is_decode]
@@ -1219,7 +1313,7 @@ class MiniVLLM:
             return None
         step = self._mixed_step(total, len(scheduled), max_q, max_ctx)
         T, S = step.T, step.S
-        buf = step.host_np
+        buf = step.host_np[parity & 1]
         per_token = buf[:3 * T].reshape(3, T)
         per_slot = buf[3 * T:].reshape(7, S)
         per_token[0] = 0
@@ -1255,7 +1349,85 @@ class MiniVLLM:
             per_slot[3, s_idx] = rows[i]
             per_slot[6, i] = at + n - 1
             at += n
-        return step.run(len(scheduled))
+        return step.run(len(scheduled), parity)
+
+    def _ensure_device_state(self) -> None:
+        """Block tables on the device, the vector every replayed step's sampler writes, and two
+        pinned vectors (with their events) through which sampled ids reach the host."""
+        if self._device_tables is None:
+            dev = _compute_device(self.model.k_cache)
+            self._device_tables = DeviceBlockTables(dev, rows=max(8, self.scheduler.max_num_seqs))
+        if self._ids_dev is None:
+            dev = self._device_tables.device
+            cap = self.scheduler.max_num_seqs + 64          # every padded batch size fits
+            self._ids_dev = torch.zeros((cap,), dtype=torch.int32, device=dev)
+            self._ids_host = [torch.zeros((cap,), dtype=torch.int32).pin_memory() for _ in range(2)]
+            self._ids_done = [torch.cuda.Event() for _ in range(2)]
+
+    def _launch_mixed(self, scheduled: List[ScheduledRequest]) -> Optional[_Flight]:
+        """Issues a step with prompt chunks through MixedStep, its sampling and the copy of the
+        sampled ids to pinned host memory, without waiting for the device; None (nothing issued)
+        when MixedStep does not serve the step."""
+        self._ensure_device_state()
+        requests = [item.request for item in scheduled]
+        parity = self._issued & 1
+        logits = self._run_mixed(scheduled, self._device_tables.sync(requests), parity)
+        if logits is None:
+            return None
+        self._issued += 1
+        self.last_logits = logits
+        n = len(requests)
+        ids = self.sampler.sample_device(logits, requests, out=self._ids_dev)
+        self._ids_host[parity][:n].copy_(ids, non_blocking=True)
+        self._ids_done[parity].record()
+        return _Flight(scheduled, self._ids_host[parity], self._ids_done[parity])
+
+    def _finish_flight(self, cur: _Flight, takes: List[bool]):
+        """Waits for an issued step's ids, completes the scheduler's bookkeeping and returns the
+        step's [(request_id, token)]."""
+        cur.done.synchronize()
+        tokens = cur.ids_host[:len(cur.scheduled)].tolist()
+        self.scheduler.resolve(cur.scheduled, takes, tokens)
+        out = []
+        release = self._device_tables.release
+        for item, took, tok in zip(cur.scheduled, takes, tokens):
+            if took:
+                req = item.request
+                out.append((req.request_id, tok))
+                if req.is_finished:
+                    release(req.request_id)
+        return out
+
+    def _step_pipelined(self, cur: _Flight):
+        """Completes the issued step `cur`, after issuing the step that follows it.
+
+        The scheduler only needs a step's token VALUES to end a request on the end-of-sequence
+        id; everything else (positions, prompt progress, finishing by length, blocks) follows from
+        the step's shape.  So the step's bookkeeping is applied first with stand-ins for the ids
+        (Scheduler.advance), the next step is scheduled and issued -- its decode rows read the ids
+        from device memory -- and only then does the host wait for the ids and patch them in
+        (Scheduler.resolve): scheduling, table upkeep and input staging overlap the device's work.
+        A request that turns out to have drawn the end-of-sequence id has one wasted row in the
+        step already issued (its result is dropped) and frees its slot one step later than the
+        step-by-step loop would; each request's tokens are the same either way."""
+        sch = self.scheduler
+        takes = sch.advance(cur.scheduled)
+        nxt = None
+        # a pure-decode phase ahead (nobody waiting, nobody in its prompt) is left to the captured
+        # decode steps, which cost the host far less
+        if self.pipeline_steps and (sch.waiting or any(r.num_computed_tokens < len(r.prompt_token_ids)
+                                                       for r in sch.running)):
+            ahead = sch.schedule()
+            if ahead:
+                nxt = self._launch_mixed(ahead)
+                if nxt is None:
+                    self._deferred = ahead
+                    self._deferrals += 1
+                else:
+                    self._ahead += 1
+        self._flight = nxt
+        sch.in_flight = 1 if (nxt is not None or self._deferred is not None) else 0
+        return self._finish_flight(cur, takes)
 
     def _decode_graph(self, nseq: int, max_context: int) -> DecodeStepGraph:
         """The captured step serving `nseq` sequences with contexts up to `max_context`: batch
@@ -1281,17 +1453,10 @@ class MiniVLLM:
     def _launch_decode(self, batch: List[Request], tokens: List[int], positions: List[int]) -> "_InflightDecode":
         """Issues one captured decode step, its sampling and the copy of the sampled ids to pinned
         host memory; nothing here waits for the device."""
-        if self._device_tables is None:
-            dev = _compute_device(self.model.k_cache)
-            self._device_tables = DeviceBlockTables(dev, rows=max(8, self.scheduler.max_num_seqs))
-        if self._ids_dev is None:
-            dev = self._device_tables.device
-            cap = self.scheduler.max_num_seqs + 64          # every padded batch size fits
-            self._ids_dev = torch.zeros((cap,), dtype=torch.int32, device=dev)
-            self._ids_host = [torch.zeros((cap,), dtype=torch.int32).pin_memory() for _ in range(2)]
-            self._ids_done = [torch.cuda.Event() for _ in range(2)]
+        self._ensure_device_state()
         rows = self._device_tables.sync(batch)
-        parity = self._launches & 1
+        parity = self._issued & 1
+        self._issued += 1
         self._launches += 1
         n = len(batch)
         logits = self.last_logits = self._decode_graph(n, max(positions) + 1).run(tokens, positions, rows, parity)
@@ -1376,30 +1541,34 @@ class MiniVLLM:
     def step(self):
         """One engine step; returns [(request_id, new_token)] for every request that
         produced a token (decode steps and the final chunk of a prompt)."""
-        if self.decode_graphs:
+        if self._flight is not None:
+            cur, self._flight = self._flight, None
+            return self._step_pipelined(cur)
+        scheduled = None
+        if self._deferred is not None:
+            # scheduled while the step before was in flight: decode items carry stand-ins for
+            # ids that have arrived since, and a request may have ended on one of them
+            scheduled, self._deferred = self._deferred, None
+            self.scheduler.in_flight = 0
+            scheduled = [item for item in scheduled if not item.request.is_finished]
+            for item in scheduled:
+                if not item.is_prefill:
+                    item.tokens = item.request.output_token_ids[-1:]
+        elif self.decode_graphs:
             fast = self._step_decode_only()
             if fast is not None:
                 return fast
-        scheduled = self.scheduler.schedule()
+        if scheduled is None:
+            scheduled = self.scheduler.schedule()
         if not scheduled:
             return []
+        if self.mixed_steps and self._mixed_supported():
+            cur = self._launch_mixed(scheduled)
+            if cur is not None:
+                return self._step_pipelined(cur)
         seq_lens = [len(item.tokens) for item in scheduled]
         prefill_flags = [item.is_prefill for item in scheduled]
         requests = [item.request for item in scheduled]
-        if self.mixed_steps and self._mixed_supported():
-            if self._device_tables is None:
-                self._device_tables = DeviceBlockTables(_compute_device(self.model.k_cache),
-                                                        rows=max(8, self.scheduler.max_num_seqs))
-            logits = self._run_mixed(scheduled, self._device_tables.sync(requests))
-            if logits is not None:
-                self.last_logits = logits
-                next_tokens = self.sampler.sample(logits, requests)
-                self.scheduler.update(scheduled, next_tokens)
-                for req in requests:
-                    if req.is_finished:
-                        self._device_tables.release(req.request_id)
-                return [(item.request.request_id, tok) for item, tok in zip(scheduled, next_tokens)
-                        if not (item.is_prefill and item.request.is_prefill)]
         # the step's flattened (token, position, slot) vectors, by array arithmetic per request:
         # positions are consecutive from item.start, slot = block_table[pos // bs] * bs + pos % bs
         bs = self.scheduler.block_size
