@@ -82,7 +82,11 @@ const char* mi355_last_error(void);
  *   max_context   host-side upper bound on context_lens (sizes the launch)
  *   D in {16,32,64,128,256}; Hq % Hkv == 0.
  *   workspace     >= mi355_paged_decode_workspace_bytes(...) bytes, 16-B aligned
- *                 (may be NULL when that function returns 0)
+ *                 (may be NULL when that function returns 0).  Its contents on entry may be
+ *                 anything and nothing in it is kept between calls: a split launch writes its
+ *                 fp32 partials there and, when it merges them itself, per-group arrival
+ *                 counters that carry a tag of the launch (so leftovers never count).  Calls
+ *                 whose kernels may overlap on the GPU must not share a workspace.
  */
 int mi355_paged_decode(void* out, const void* q, int64_t q_stride_seq,
                        const void* k_cache, const void* v_cache,
@@ -94,7 +98,7 @@ int mi355_paged_decode(void* out, const void* q, int64_t q_stride_seq,
                        float scale, int32_t dtype,
                        void* workspace, size_t workspace_bytes, void* stream);
 
-/* Scratch bytes mi355_paged_decode needs for this shape (split-KV partials). */
+/* Scratch bytes mi355_paged_decode needs for this shape (split-KV partials and arrival counters). */
 size_t mi355_paged_decode_workspace_bytes(int32_t B, int32_t Hq, int32_t Hkv, int32_t D,
                                           int32_t block_size, int32_t max_context, int32_t dtype);
 
@@ -111,7 +115,8 @@ size_t mi355_paged_decode_workspace_bytes(int32_t B, int32_t Hq, int32_t Hkv, in
  *     MI355_STATIC_SCRATCH_BYTES is rejected with MI355_EWORKSPACE before any launch.
  *   - All calls on one GPU share the array: calls whose kernels may overlap on that GPU
  *     (different streams, different threads) race on it.  Calls on one stream are safe, and
- *     nothing in the array needs clearing between calls: every record a call reads, it wrote.
+ *     nothing in the array needs clearing between calls: every record a call reads, it wrote,
+ *     and arrival counters only count under the tag of the launch that reads them.
  */
 #define MI355_STATIC_SCRATCH_BYTES (16u << 20)
 int mi355_paged_decode_static(void* out, const void* q, int64_t q_stride_seq,

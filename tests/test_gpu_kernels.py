@@ -1024,3 +1024,62 @@ def test_sampling_temperature_spread(ops, device):
     low = ops.sample_topk_topp(logits, torch.full((200,), 0.1, device=device), None, None, seed=1)
     high = ops.sample_topk_topp(logits, torch.full((200,), 10.0, device=device), None, None, seed=1)
     assert len(set(low.cpu().tolist())) < len(set(high.cpu().tolist()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('B,Hq,Hkv,D,max_ctx', [(1, 8, 8, 64, 8192), (3, 8, 8, 64, 20000), (16, 8, 8, 128, 4096),
+                                                (2, 4, 2, 64, 6000), (5, 2, 1, 32, 3000), (1, 8, 8, 64, 70000)])
+def test_token_splits_merged_in_the_launch_match_the_second_launch(ops, device, dtype, B, Hq, Hkv, D, max_ctx):
+    """The VALU decode kernel merges its token splits itself (the last workgroup of a group to finish
+    combines the partials) -- against the two-launch form (MI355_DECODE_FUSED_MERGE=0), call after
+    call on one workspace whose contents are scrambled in between (zeros, all-ones, random bits: the
+    arrival cells must not depend on what the workspace held), ragged contexts including an empty
+    sequence, and replays of one captured launch."""
+    bs = 16
+    g = torch.Generator(device=device).manual_seed(B * 131 + D)
+    per = -(-max_ctx // bs)
+    nb = B * per + 3
+    kc = torch.randn((nb, Hkv, bs, D), generator=g, device=device).to(dtype)
+    vc = torch.randn((nb, Hkv, bs, D), generator=g, device=device).to(dtype)
+    bt = torch.randperm(nb, generator=g, device=device)[:B * per].view(B, per).to(torch.int32).contiguous()
+    need = ops._lib.load().mi355_paged_decode_workspace_bytes(B, Hq, Hkv, D, bs, max_ctx, ops._DTYPE_CODE[dtype])
+    assert need > 0, "the case is meant to split tokens across workgroups"
+    tol = dict(rtol=2e-5, atol=2e-6) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-3)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    for it in range(12):
+        q = torch.randn((B, Hq, D), generator=g, device=device).to(dtype)
+        ctx = torch.randint(1, max_ctx + 1, (B,), generator=g, device=device).to(torch.int32)
+        ctx[it % B] = max_ctx if it % 3 else 0
+        with ops.debug_knob('MI355_DECODE_FUSED_MERGE', 0):
+            want = ops.paged_decode(q, kc, vc, bt, ctx, max_ctx)
+        ws, _ = ops._workspace(device, need, stream)
+        if it % 4 == 0:
+            ws.zero_()
+        elif it % 4 == 1:
+            ws.fill_(255)
+        elif it % 4 == 2:
+            ws.view(torch.int64)[:need // 8].random_(-2 ** 62, 2 ** 62, generator=g)
+        with ops.debug_knob('MI355_DECODE_FUSED_MERGE', 65535):      # (by default only up to 8 splits)
+            got = ops.paged_decode(q, kc, vc, bt, ctx, max_ctx)
+        torch.testing.assert_close(got.float(), want.float(), **tol)
+        assert not got[it % B].float().abs().sum().item() if not it % 3 else True
+
+    q = torch.randn((B, Hq, D), generator=g, device=device).to(dtype)
+    ctx = torch.full((B,), max_ctx, dtype=torch.int32, device=device)
+    out = torch.empty_like(q)
+    side = torch.cuda.Stream(device=device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(side), ops.debug_knob('MI355_DECODE_FUSED_MERGE', 65535):
+        ops.paged_decode(q, kc, vc, bt, ctx, max_ctx, out=out)
+    torch.cuda.current_stream(device).wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph), ops.debug_knob('MI355_DECODE_FUSED_MERGE', 65535):
+        ops.paged_decode(q, kc, vc, bt, ctx, max_ctx, out=out)
+    for it in range(6):
+        q.copy_(torch.randn((B, Hq, D), generator=g, device=device).to(dtype))
+        ctx.copy_(torch.randint(1, max_ctx + 1, (B,), generator=g, device=device).to(torch.int32))
+        graph.replay()
+        with ops.debug_knob('MI355_DECODE_FUSED_MERGE', 0):
+            want = ops.paged_decode(q, kc, vc, bt, ctx, max_ctx)
+        torch.testing.assert_close(out.float(), want.float(), **tol)

@@ -36,6 +36,7 @@ enum Knob {
   kKnobMlaManyHeads,      // MI355_MLA_MANY_HEADS      1: 64 heads per MLA workgroup above 16 heads
   kKnobMlaTargetWgs,      // MI355_MLA_TARGET_WGS      0: planned; else workgroups an MLA launch aims for
   kKnobPrefillF32Mfma,    // MI355_PREFILL_F32_MFMA    1: fp32 prompts (head_dim 32 / 64 / 128) on the fp32 matrix instruction
+  kKnobDecodeFusedMerge,  // MI355_DECODE_FUSED_MERGE  most token splits the VALU decode kernel merges in its own launch (0: never)
   kKnobCount
 };
 int knob(Knob k);

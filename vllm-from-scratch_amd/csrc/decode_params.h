@@ -36,11 +36,16 @@ struct DecodeParams {
   const int32_t* seg_pos0;
   int n_qt, tq, hgp_shift;
   int max_q;   // host-side bound on seg_len the grid was sized for; device values are clamped to it
+  // Token splits merged inside the VALU kernel (null: a second launch merges them): one 64-bit
+  // arrival cell per (sequence, kv-head group, q-head chunk), holding (launch tag << 16) | arrivals.
+  unsigned long long* counters = nullptr;
+  unsigned long long epoch = 0;
 };
 
 struct DecodePlan {
   int nw, hpw, sub, hgroups, G, qchunks, tps, nsplit;
   bool mfma;  // grouped-query shape served by the matrix-core kernel
+  bool fused_merge = false;  // token splits are merged by the last workgroup of each group to finish
   size_t lds_bytes, lds_bt_bytes, ws_bytes;
 };
 
