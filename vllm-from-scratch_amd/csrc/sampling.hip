@@ -255,6 +255,7 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
   // cut search state (see the filter section)
   __shared__ unsigned long long s_hist[kHistBins];
   __shared__ unsigned long long s_above;
+  __shared__ unsigned long long s_wsum[kMaxWaves];
   __shared__ int s_cutbin, s_cutcount;
   constexpr int kTieCap = 64;
   __shared__ int s_tie_i[kTieCap];
@@ -474,7 +475,7 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
     uint32_t prefix = 0;               // the bits fixed so far
 #pragma unroll
     for (int L = 0; L < 3; ++L) {
-      const int shift = kLevelShift[L], nbins = 1 << kLevelBits[L], per = nbins / kWave;
+      const int shift = kLevelShift[L], nbins = 1 << kLevelBits[L];
       for (int i = tid; i < nbins; i += nt) s_hist[i] = 0ull;
       __syncthreads();
       for_each([&](float q, int) {
@@ -484,38 +485,43 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
                     (1ull << 41) + (unsigned long long)(q * 1099511627776.0f));   // count | q * 2^40
       });
       __syncthreads();
-      if (wave == 0) {
-        // lane l owns bins [l * per, (l + 1) * per); suffix sums over the lanes above it, then a walk
-        // down its own bins.  `run` = everything above the bin.  Passing bins form an upper range.
-        // The bins are re-read from LDS on each use: held in registers next to the thread's slice
-        // of the row they overflow the 128-register budget of a 1024-thread workgroup.
-        const int first = lane * per;
+      {
+        // Every thread owns nbins / nt consecutive bins (at least one; threads past the last bin
+        // idle): suffix sums over the threads above it -- within the wave by shuffles, across waves
+        // through LDS -- then a walk down its own bins.  `run` = everything above the bin.  Passing
+        // bins form an upper range, so the cut bin is the lowest one that passes.  (One wave
+        // scanning all 2048 bins alone, 32 per lane, took 3-4 us of a level's 6-9.)
+        const int bpt = nbins >= nt ? nbins / nt : 1;
+        const int first = tid * bpt;
+        const bool has = first < nbins;
         unsigned long long own = 0ull;
-#pragma unroll 8
-        for (int i = 0; i < per; ++i) own += s_hist[first + i];
-        unsigned long long incl = own;    // inclusive suffix scan: lanes >= l
+        if (has)
+          for (int i = 0; i < bpt; ++i) own += s_hist[first + i];
+        unsigned long long incl = own;    // inclusive suffix scan: lanes >= l of this wave
 #pragma unroll
         for (int off = 1; off < kWave; off <<= 1) {
           const unsigned long long o = __shfl_down(incl, off);
           if (lane + off < kWave) incl += o;
         }
-        const unsigned long long above_lane = acc + (incl - own);
-        unsigned long long run = above_lane;
+        if (lane == 0) s_wsum[wave] = incl;
+        __syncthreads();
+        unsigned long long above = acc + (incl - own);
+        for (int w = wave + 1; w < (nt >> 6); ++w) above += s_wsum[w];
+        unsigned long long run = above;
         int best = 0x7fffffff, top = -1;
-#pragma unroll 4
-        for (int i = per - 1; i >= 0; --i) {
-          const unsigned long long h = s_hist[first + i];
-          if (ok((float)(run & kMassMask) * 0x1p-40f, (int)(run >> 41))) best = first + i;
-          if (h != 0ull && top < 0) top = first + i;
-          run += h;
-        }
-        const int best_all = wave_reduce(best, mini);
-        const int top_all = wave_reduce(top, maxi);
-        // nothing passes (top_p <= 0): the largest value alone survives -> follow the top bin
-        const int sel = best_all != 0x7fffffff ? best_all : max(top_all, 0);
-        if (lane == sel / per) {
-          unsigned long long r = above_lane;
-          for (int bin = first + per - 1; bin > sel; --bin) r += s_hist[bin];
+        if (has)
+          for (int i = bpt - 1; i >= 0; --i) {
+            const unsigned long long h = s_hist[first + i];
+            if (ok((float)(run & kMassMask) * 0x1p-40f, (int)(run >> 41))) best = first + i;
+            if (h != 0ull && top < 0) top = first + i;
+            run += h;
+          }
+        int sel = block_reduce(best, mini, xch, slot);
+        if (sel == 0x7fffffff)   // nothing passes (top_p <= 0): the largest value alone survives -> follow the top bin
+          sel = max(block_reduce(top, maxi, xch, slot), 0);
+        if (has && sel >= first && sel < first + bpt) {
+          unsigned long long r = above;
+          for (int bin = first + bpt - 1; bin > sel; --bin) r += s_hist[bin];
           s_cutbin = sel;
           s_above = r;
           s_cutcount = (int)(s_hist[sel] >> 41);
