@@ -257,6 +257,9 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
   __shared__ unsigned long long s_above;
   __shared__ unsigned long long s_wsum[kMaxWaves];
   __shared__ int s_cutbin, s_cutcount;
+  constexpr int kListCap = 4096;
+  __shared__ float s_list[kListCap];
+  __shared__ int s_list_n;
   constexpr int kTieCap = 64;
   __shared__ int s_tie_i[kTieCap];
   __shared__ int s_tie_n;
@@ -473,17 +476,31 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
     static_assert(kHistShift == 19 && kHistBins == 2048, "the three fields must tile the 32 bits");
     unsigned long long acc = 0ull;     // packed (count | mass) of everything above the prefix's range
     uint32_t prefix = 0;               // the bits fixed so far
+    // After the first level only the elements of its cut bin matter.  When they fit (the usual
+    // case: a few hundred of 32000) they are copied to an LDS list once, and the other two levels
+    // walk the list -- one element per thread -- instead of the whole row again (for a
+    // register-resident row that is 32 compares per thread per level, for a streamed row another
+    // trip through memory).
+    int listed = -1;                   // >= 0: the candidates are s_list[0 .. listed)
+    auto tally = [&](float q, int shift, int nbins) {
+      atomicAdd(&s_hist[(__builtin_bit_cast(uint32_t, q) >> shift) & (uint32_t)(nbins - 1)],
+                (1ull << 41) + (unsigned long long)(q * 1099511627776.0f));   // count | q * 2^40
+    };
 #pragma unroll
     for (int L = 0; L < 3; ++L) {
       const int shift = kLevelShift[L], nbins = 1 << kLevelBits[L];
       for (int i = tid; i < nbins; i += nt) s_hist[i] = 0ull;
       __syncthreads();
-      for_each([&](float q, int) {
-        const uint32_t bits = __builtin_bit_cast(uint32_t, q);
-        if (L == 0 || (bits >> (shift + kLevelBits[L])) == prefix)
-          atomicAdd(&s_hist[(bits >> shift) & (uint32_t)(nbins - 1)],
-                    (1ull << 41) + (unsigned long long)(q * 1099511627776.0f));   // count | q * 2^40
-      });
+      if (L > 0 && listed >= 0) {
+        for (int i = tid; i < listed; i += nt) {
+          const float q = s_list[i];
+          if (L == 1 || (__builtin_bit_cast(uint32_t, q) >> (shift + kLevelBits[L])) == prefix) tally(q, shift, nbins);
+        }
+      } else {
+        for_each([&](float q, int) {
+          if (L == 0 || (__builtin_bit_cast(uint32_t, q) >> (shift + kLevelBits[L])) == prefix) tally(q, shift, nbins);
+        });
+      }
       __syncthreads();
       {
         // Every thread owns nbins / nt consecutive bins (at least one; threads past the last bin
@@ -530,6 +547,15 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
       __syncthreads();
       prefix = (prefix << kLevelBits[L]) | (uint32_t)s_cutbin;
       acc = s_above;
+      if (L == 0 && s_cutcount <= kListCap) {     // (the bin's exact population: the list cannot overflow)
+        listed = s_cutcount;
+        if (tid == 0) s_list_n = 0;
+        __syncthreads();
+        for_each([&](float q, int) {
+          if ((__builtin_bit_cast(uint32_t, q) >> kHistShift) == prefix) s_list[atomicAdd(&s_list_n, 1)] = q;
+        });
+        // (the next level's barrier after zeroing the bins orders these writes before its reads)
+      }
     }
     vstar = __builtin_bit_cast(float, prefix);
     const int ties = s_cutcount;
