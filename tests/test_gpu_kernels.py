@@ -1029,10 +1029,11 @@ def test_sampling_temperature_spread(ops, device):
 @pytest.mark.gpu
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize('B,Hq,Hkv,D,max_ctx', [(1, 8, 8, 64, 8192), (3, 8, 8, 64, 20000), (16, 8, 8, 128, 4096),
-                                                (2, 4, 2, 64, 6000), (5, 2, 1, 32, 3000), (1, 8, 8, 64, 70000)])
+                                                (2, 4, 2, 64, 6000), (5, 2, 1, 32, 3000), (1, 8, 8, 64, 70000),
+                                                (3, 32, 8, 128, 9000), (2, 16, 2, 64, 5000), (4, 40, 8, 128, 3000)])
 def test_token_splits_merged_in_the_launch_match_the_second_launch(ops, device, dtype, B, Hq, Hkv, D, max_ctx):
-    """The VALU decode kernel merges its token splits itself (the last workgroup of a group to finish
-    combines the partials) -- against the two-launch form (MI355_DECODE_FUSED_MERGE=0), call after
+    """The decode kernels (VALU, and the matrix-core one for grouped-query 16-bit shapes) merge their
+    token splits themselves (the last workgroup of a group to finish combines the partials) -- against the two-launch form (MI355_DECODE_FUSED_MERGE=0), call after
     call on one workspace whose contents are scrambled in between (zeros, all-ones, random bits: the
     arrival cells must not depend on what the workspace held), ragged contexts including an empty
     sequence, and replays of one captured launch."""

@@ -1,5 +1,5 @@
 """Split-token decode with the merge inside the launch against the two-launch form
-(MI355_DECODE_FUSED_MERGE=65535 / 0), same process, alternating:  python tools/ab_fused_merge.py"""
+(MI355_DECODE_FUSED_MERGE=65535 / 0), same process, alternating:  python tools/ab_fused_merge.py [Hq Hkv D]"""
 import os
 import sys
 
@@ -9,8 +9,7 @@ from mi355_paged import ops
 
 dev = torch.device('cuda', 0)
 BS = 16
-Hq = Hkv = 8
-D = 64
+Hq, Hkv, D = ([int(x) for x in sys.argv[1:]] + [8, 8, 64])[:3]      # e.g. 32 8 128: the matrix-core kernel
 for B, S in ((1, 2048), (1, 8192), (1, 32768), (1, 131072), (2, 8192), (4, 8192), (4, 32768), (8, 4096), (16, 8192), (16, 32768),
              (32, 4096)):
     g = torch.Generator(device=dev).manual_seed(0)
@@ -43,6 +42,6 @@ for B, S in ((1, 2048), (1, 8192), (1, 32768), (1, 131072), (2, 8192), (4, 8192)
                 torch.cuda.synchronize()
                 res[fused].append(a.elapsed_time(b) / n * 1e3)
     med = {k: sorted(v)[len(v) // 2] for k, v in res.items()}
-    print(f"B={B:3d} ctx={S:6d} ({nbytes / 1e6:7.1f} MB): two launches {med[0]:6.1f} us, one launch {med[1]:6.1f} us "
+    print(f"Hq={Hq} Hkv={Hkv} D={D} B={B:3d} ctx={S:6d} ({nbytes / 1e6:7.1f} MB): two launches {med[0]:6.1f} us, one launch {med[1]:6.1f} us "
           f"({nbytes / med[1] / 1e3:5.0f} GB/s)", flush=True)
     del pools

@@ -28,6 +28,7 @@
 #include <random>
 
 #include "common.h"
+#include "decode_merge.h"
 #include "decode_params.h"
 
 namespace mi355 {
@@ -42,20 +43,6 @@ struct Geo {
   static constexpr int TPL = kWave / LPT;    // tokens per wave load
   static_assert(LPT >= 1 && LPT <= kWave && (LPT & (LPT - 1)) == 0, "unsupported head_dim");
 };
-
-// Two floats written through to / read from device-coherent memory (relaxed 8-byte atomics at
-// agent scope: sc1 accesses that neither leave dirty lines in, nor hit stale lines of, the
-// per-XCD L2), for data that workgroups of one launch hand to each other.
-__device__ inline void store_coherent2(float* dst, float a, float b) {
-  const unsigned long long v = ((unsigned long long)__float_as_uint(b) << 32) | __float_as_uint(a);
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ inline void load_coherent2(const float* src, float& a, float& b) {
-  const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(src), __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT);
-  a = __uint_as_float((unsigned)v);
-  b = __uint_as_float((unsigned)(v >> 32));
-}
 
 // ROWS (causal mode only): the G slots of a wave are G consecutive query rows of one sequence and
 // one query head instead of G query heads of one row.  They share every K/V load -- row r reads
@@ -121,11 +108,7 @@ __global__ void __launch_bounds__(kMaxThreads) paged_decode_kernel(const DecodeP
   // split 0 always takes part, so that an empty sequence still gets its (zero) output row.
   const bool fused = !ROWS && p.counters != nullptr;
   if (p.nsplit > 1 && t0 >= ctx && !(fused && sp == 0)) return;
-  if (fused && sp == 0 && tid == 0) {
-    // tag the group's arrival cell for this launch (see the end of the kernel); nothing waits for it
-    unsigned long long* cell = p.counters + ((int64_t)b * p.hgroups + hg) * p.qchunks + qc;
-    (void)__hip_atomic_fetch_max(cell, p.epoch << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  if (fused && sp == 0 && tid == 0) tag_arrival_cell(p, b, hg, qc);
   const int wg_end = min(ctx, t0 + p.tps);
 
   auto block_of = [&](int t) { return p.bs_shift >= 0 ? (t >> p.bs_shift) : (t / p.block_size); };
@@ -323,104 +306,13 @@ __global__ void __launch_bounds__(kMaxThreads) paged_decode_kernel(const DecodeP
     }
   }
 
-  // Token splits merged in this launch: the workgroups of a (sequence, head group, q chunk) count
-  // their arrivals in a 64-bit cell of the workspace, and the one that arrives last combines the
-  // group's partials.  Partials travel through device-coherent accesses (store_coherent2 /
-  // load_coherent2) instead of device-scope fences, whose write-back and invalidation of the whole
-  // L2 cost several times what the merge saves.
-  // The workspace is not required to be zeroed: a cell counts only while its upper 48 bits equal
-  // this launch's tag.  Split 0 raises the cell to (tag << 16) when it starts (an atomic max: it
-  // cannot undo arrivals), and an arrival is normally one fetch-add.  A workgroup that finds
-  // another tag -- it got there before split 0's max did, or the cell held something larger than
-  // any tag -- has added 1 to a value nobody reads and arrives again by compare-and-swap, which
-  // installs the tag itself.  The last arriver clears the cell, so that a replay of the same
-  // launch (a captured graph) starts over.
+  // Token splits merged in this launch (decode_merge.h): the workgroup that arrives last
+  // combines the group's partials.
   if constexpr (!ROWS) {
     if (!fused) return;
-    constexpr int kVec = 4, kDv = D / kVec, kGroups = kMaxThreads / kDv;
-    static_assert(kDv <= 64 && kMaxThreads % kDv == 0, "head_dim");
-    __shared__ float s_red[kGroups][kDv][kVec + 1];
-    __shared__ float s_max[kGroups];
-    __shared__ int s_last;
-    // every wave's partials have been written through (vmcnt counts stores until they are
-    // acknowledged) before the workgroup's arrival is counted
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-    __syncthreads();
     const int nvalid = max(1, min(p.nsplit, (ctx + p.tps - 1) / p.tps));
-    if (tid == 0) {
-      unsigned long long* cell = p.counters + ((int64_t)b * p.hgroups + hg) * p.qchunks + qc;
-      unsigned long long seen = __hip_atomic_fetch_add(cell, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      unsigned long long next = seen + 1;
-      if ((seen >> 16) != p.epoch) {
-        seen = next;
-        do {   // every failed exchange means another workgroup of the group has arrived: at most nsplit rounds
-          next = (seen >> 16) == p.epoch ? seen + 1 : ((p.epoch << 16) | 1ull);
-        } while (!__hip_atomic_compare_exchange_strong(cell, &seen, next, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_AGENT));
-      }
-      const int last = (int)(next & 0xffffu) == nvalid;
-      if (last) __hip_atomic_store(cell, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_last = last;
-    }
-    __syncthreads();
-    if (!s_last) return;
-
-    const int dv = tid % kDv, grp = tid / kDv;
-    const int heads = p.hpw * G;
-    for (int h = 0; h < heads; ++h) {
-      const int slot = h / G, gi = h % G;
-      if (qc * G + gi >= p.gq) continue;
-      const int64_t bh = (int64_t)b * p.Hq + (int64_t)(hg * p.hpw + slot) * p.gq + qc * G + gi;
-      const float* ml = p.ws_ml + bh * p.nsplit * 2;
-      const float* pa = p.ws_acc + bh * p.nsplit * D + dv * kVec;
-      // one pass: every (split group, 4 dims) thread folds its splits with a running maximum of
-      // its own; the groups then meet in LDS, each carrying its maximum
-      float M = kNegBig, den = 0.f, o[kVec] = {0.f, 0.f, 0.f, 0.f};
-      for (int s = grp; s < nvalid; s += kGroups) {
-        float ms, ls, a[kVec];
-        load_coherent2(ml + 2 * s, ms, ls);
-        load_coherent2(pa + (size_t)s * D, a[0], a[1]);
-        load_coherent2(pa + (size_t)s * D + 2, a[2], a[3]);
-        const float Mn = fmaxf(M, ms);
-        const float fo = fast_exp2(M - Mn), fn = fast_exp2(ms - Mn);
-        M = Mn;
-        den = __builtin_fmaf(ls, fn, den * fo);
-#pragma unroll
-        for (int e = 0; e < kVec; ++e) o[e] = __builtin_fmaf(a[e], fn, o[e] * fo);
-      }
-#pragma unroll
-      for (int e = 0; e < kVec; ++e) s_red[grp][dv][e] = o[e];
-      s_red[grp][dv][kVec] = den;
-      if (dv == 0) s_max[grp] = M;
-      __syncthreads();
-      if (grp == 0) {
-        // fixed order over the groups: the result does not depend on timing
-        const int used = min(kGroups, nvalid);
-        float Mall = M;
-        for (int g = 1; g < used; ++g) Mall = fmaxf(Mall, s_max[g]);
-        const float f0 = fast_exp2(M - Mall);
-        den *= f0;
-#pragma unroll
-        for (int e = 0; e < kVec; ++e) o[e] *= f0;
-        for (int g = 1; g < used; ++g) {
-          const float f = fast_exp2(s_max[g] - Mall);
-#pragma unroll
-          for (int e = 0; e < kVec; ++e) o[e] = __builtin_fmaf(s_red[g][dv][e], f, o[e]);
-          den = __builtin_fmaf(s_red[g][dv][kVec], f, den);
-        }
-        const float inv = den > 0.f ? 1.f / den : 0.f;
-        typename Tag::elem_t* dst = static_cast<typename Tag::elem_t*>(p.out) + bh * D + dv * kVec;
-        if constexpr (Tag::kBytes == 4) {
-          *reinterpret_cast<f32x4*>(dst) = f32x4{o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv};
-        } else {
-          float lo[8] = {o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv, 0.f, 0.f, 0.f, 0.f};
-          const u32x4 packed = Tag::pack(lo);
-          *reinterpret_cast<uint2*>(dst) = make_uint2(packed[0], packed[1]);
-        }
-      }
-      __syncthreads();   // s_red and s_max are reused by the next head
-    }
+    if (!arrived_last(p, b, hg, qc, nvalid, tid)) return;
+    merge_splits_in_workgroup<Tag, D, kMaxThreads>(p, b, hg, qc, G, nvalid, tid);
   }
 }
 
@@ -585,12 +477,12 @@ int make_plan(int B, int Hq, int Hkv, int D, int block_size, int max_context, in
   pl.lds_bytes = pl.mfma ? decode_gqa_lds_bytes(D, pl.sub, pl.lds_bt_bytes)
                          : pl.lds_bt_bytes + (pl.sub > 1 ? (size_t)pl.nw * pl.G * (D + 2) * 4 : 0);
   pl.ws_bytes = pl.nsplit > 1 ? (size_t)B * Hq * pl.nsplit * (D + 2) * sizeof(float) : 0;
-  // Up to MI355_DECODE_FUSED_MERGE splits (0: never) the VALU kernel merges its token splits
-  // itself (arrival cells behind the partials): with the host queued ahead that saves 1-2 us of
+  // Up to MI355_DECODE_FUSED_MERGE splits (0: never) the decode kernels merge their token splits
+  // themselves (decode_merge.h; arrival cells behind the partials): with the host queued ahead that saves 1-2 us of
   // 17-47 at 2-8 splits; from 16 splits on, the last workgroup's serial tail (arrival, then
   // reading every partial) takes longer than the wide merge kernel's launch.
   const int fuse_up_to = knob(kKnobDecodeFusedMerge);
-  pl.fused_merge = pl.nsplit > 1 && pl.nsplit <= (fuse_up_to < 65535 ? fuse_up_to : 65535) && !pl.mfma && !causal;
+  pl.fused_merge = pl.nsplit > 1 && pl.nsplit <= (fuse_up_to < 65535 ? fuse_up_to : 65535) && !causal;
   if (pl.fused_merge) pl.ws_bytes += (size_t)B * pl.hgroups * pl.qchunks * sizeof(unsigned long long);
   *plan = pl;
   return 0;
@@ -656,7 +548,7 @@ int dispatch_causal_rows(int D, const DecodeParams& p, size_t lds_bytes, hipStre
 // Matrix-core kernel for grouped-query shapes (+ the shared merge kernel when tokens are split).
 int launch_gqa(const DecodeParams& p, const DecodePlan& pl, int D, int dtype, hipStream_t s) {
   if (int rc = decode_gqa_launch(p, pl, D, dtype, s)) return rc;
-  if (p.nsplit == 1) return 0;
+  if (p.nsplit == 1 || p.counters) return 0;   // (token splits merged inside the launch)
   if (dtype == MI355_BF16) return D == 64 ? launch_merge<BF16, 64>(p, s) : launch_merge<BF16, 128>(p, s);
   return D == 64 ? launch_merge<F16, 64>(p, s) : launch_merge<F16, 128>(p, s);
 }

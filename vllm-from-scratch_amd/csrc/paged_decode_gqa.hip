@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "decode_merge.h"
 #include "decode_params.h"
 
 namespace mi355 {
@@ -117,7 +118,11 @@ __global__ void __launch_bounds__(kGqaWaves* kWave, 2) paged_decode_gqa_kernel(c
     col_ok = head_in_group < p.gq;
   }
   const int t0 = sp * p.tps;
-  if (p.nsplit > 1 && t0 >= ctx) return;  // the merge kernel skips splits past the context
+  // Splits past the context do nothing and the merge skips them; with the merge in this launch
+  // (decode_merge.h) split 0 always takes part, so that an empty sequence still gets its zero row.
+  const bool fused = !APPEND && p.counters != nullptr;
+  if (p.nsplit > 1 && t0 >= ctx && !(fused && sp == 0)) return;
+  if (fused && sp == 0 && tid == 0) tag_arrival_cell(p, b, hg, qc);
   const int wg_end = min(ctx, t0 + p.tps);
   auto block_of = [&](int t) { return p.bs_shift >= 0 ? (t >> p.bs_shift) : (t / p.block_size); };
 
@@ -291,8 +296,11 @@ __global__ void __launch_bounds__(kGqaWaves* kWave, 2) paged_decode_gqa_kernel(c
       }
     }
   }
-  if (sb != 0 || !head_ok) return;
-  if (p.nsplit == 1) {
+  const bool owner = sb == 0 && head_ok;
+  if (!owner && !fused) return;
+  if (!owner) {
+    // (a lane without an output column of its own still takes part in the merge below)
+  } else if (p.nsplit == 1) {
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
     char* dst = static_cast<char*>(p.out) + (((int64_t)qrow * p.Hq + hq) * D + 4 * g) * 2;
 #pragma unroll
@@ -303,12 +311,27 @@ __global__ void __launch_bounds__(kGqaWaves* kWave, 2) paged_decode_gqa_kernel(c
   } else {
     const int64_t rec = ((int64_t)qrow * p.Hq + hq) * p.nsplit + sp;
     float* dst = p.ws_acc + rec * D + 4 * g;
+    if (fused) {
 #pragma unroll
-    for (int i = 0; i < OT; ++i) *reinterpret_cast<f32x4*>(dst + 16 * i) = o[i];
-    if (g == 0) {
-      p.ws_ml[rec * 2] = m_run;
-      p.ws_ml[rec * 2 + 1] = l_run;
+      for (int i = 0; i < OT; ++i) {
+        store_coherent2(dst + 16 * i, o[i][0], o[i][1]);
+        store_coherent2(dst + 16 * i + 2, o[i][2], o[i][3]);
+      }
+      if (g == 0) store_coherent2(p.ws_ml + rec * 2, m_run, l_run);
+    } else {
+#pragma unroll
+      for (int i = 0; i < OT; ++i) *reinterpret_cast<f32x4*>(dst + 16 * i) = o[i];
+      if (g == 0) {
+        p.ws_ml[rec * 2] = m_run;
+        p.ws_ml[rec * 2 + 1] = l_run;
+      }
     }
+  }
+  if constexpr (!APPEND) {
+    if (!fused) return;
+    const int nvalid = max(1, min(p.nsplit, (ctx + p.tps - 1) / p.tps));
+    if (!arrived_last(p, b, hg, qc, nvalid, tid)) return;
+    merge_splits_in_workgroup<Tag, D, kGqaWaves * kWave>(p, b, hg, qc, kGqaHeads, nvalid, tid);
   }
 }
 
