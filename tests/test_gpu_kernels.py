@@ -1084,3 +1084,37 @@ def test_token_splits_merged_in_the_launch_match_the_second_launch(ops, device, 
         with ops.debug_knob('MI355_DECODE_FUSED_MERGE', 0):
             want = ops.paged_decode(q, kc, vc, bt, ctx, max_ctx)
         torch.testing.assert_close(out.float(), want.float(), **tol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype,D,Hq,Hkv', [(torch.bfloat16, 64, 8, 8), (torch.float32, 64, 8, 8), (torch.bfloat16, 128, 32, 8),
+                                            (torch.float16, 128, 4, 4)])
+def test_heads_spread_over_workgroups_match_the_plain_plan(ops, device, dtype, D, Hq, Hkv):
+    """A launch without token splits over a cache with contiguous (block, head) tiles spreads its
+    kv heads over up to MI355_PAGED_BALANCE_WGS workgroups (ragged batches finish together); the
+    result equals the plain plan's (8 heads per workgroup) up to the order of the sub-range merge,
+    for ragged contexts including empty and full ones, and the interleaved layout keeps the plain plan."""
+    bs, B, S = 16, 96, 2048
+    g = torch.Generator(device=device).manual_seed(D + Hq)
+    per = S // bs
+    nb = B * per + 5
+    kc = torch.randn((nb, Hkv, bs, D), generator=g, device=device).to(dtype)
+    vc = torch.randn((nb, Hkv, bs, D), generator=g, device=device).to(dtype)
+    bt = torch.randperm(nb, generator=g, device=device)[:B * per].view(B, per).to(torch.int32).contiguous()
+    q = torch.randn((B, Hq, D), generator=g, device=device).to(dtype)
+    ctx = torch.randint(1, S + 1, (B,), generator=g, device=device).to(torch.int32)
+    ctx[0], ctx[1], ctx[2] = 0, S, 1
+    assert ops._lib.load().mi355_paged_decode_workspace_bytes(B, Hq, Hkv, D, bs, S, ops._DTYPE_CODE[dtype]) == 0
+    with ops.debug_knob('MI355_PAGED_BALANCE_WGS', 0):
+        plain = ops.paged_decode(q, kc, vc, bt, ctx, S)
+    spread = ops.paged_decode(q, kc, vc, bt, ctx, S)
+    tol = dict(rtol=1e-5, atol=2e-6) if dtype == torch.float32 else dict(rtol=1.6e-2, atol=2e-3)
+    torch.testing.assert_close(spread.float(), plain.float(), **tol)
+    assert not spread[0].float().abs().sum().item()
+    # [block][row][head][d]: one head per workgroup would read 128-byte pieces, so the plan stays
+    kc2, vc2 = kc.permute(0, 2, 1, 3).contiguous(), vc.permute(0, 2, 1, 3).contiguous()
+    a = ops.paged_decode(q, kc2, vc2, bt, ctx, S, layout='NSHD')
+    with ops.debug_knob('MI355_PAGED_BALANCE_WGS', 0):
+        b = ops.paged_decode(q, kc2, vc2, bt, ctx, S, layout='NSHD')
+    assert torch.equal(a, b)
+    torch.testing.assert_close(a.float(), plain.float(), **tol)

@@ -51,6 +51,8 @@ step secondary benchmarks
   MI355_MLA_MANY_HEADS=0 MLA_TARGETS=0 timeout -k 10 120 python3 tools/bench_mla.py 128 128 4096 | tail -1 | sed 's/^/16 heads per workgroup: /'
   timeout -k 10 200 python3 tools/bench_small_batch.py
   timeout -k 10 200 python3 tools/ab_fused_merge.py
+  timeout -k 10 200 python3 tools/bench_ragged.py
+  timeout -k 10 200 python3 tools/ab_balance.py
   for a in "16 2048 8 8 64" "2 16384 8 8 64" "16 2048 32 8 128" "4 8192 32 8 128" "64 512 32 8 128"; do BENCH_MFMA_ONLY=1 timeout -k 10 120 python3 tools/bench_prefill.py $a; done
   timeout -k 10 120 python3 tools/bench_prefill_fp32.py 16 2048 8 8 64
   timeout -k 10 120 python3 tools/bench_prefill_fp32.py 16 2048 4 4 32

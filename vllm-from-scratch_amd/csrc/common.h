@@ -37,6 +37,7 @@ enum Knob {
   kKnobMlaTargetWgs,      // MI355_MLA_TARGET_WGS      0: planned; else workgroups an MLA launch aims for
   kKnobPrefillF32Mfma,    // MI355_PREFILL_F32_MFMA    1: fp32 prompts (head_dim 32 / 64 / 128) on the fp32 matrix instruction
   kKnobDecodeFusedMerge,  // MI355_DECODE_FUSED_MERGE  most token splits the VALU decode kernel merges in its own launch (0: never)
+  kKnobPagedBalanceWgs,   // MI355_PAGED_BALANCE_WGS   workgroups a decode launch spreads its kv heads over for ragged batches (0: off)
   kKnobCount
 };
 int knob(Knob k);

@@ -403,6 +403,8 @@ __global__ void __launch_bounds__(256) paged_decode_merge_wide_kernel(const Deco
   }
 }
 
+constexpr int kBalanceSteps = 8;      // pipeline steps every wave keeps when heads are spread for balance
+constexpr int64_t kSpreadTileBytes = 2048;   // smallest contiguous (block, head) tile for which heads are spread
 constexpr int kWideMergeSplits = 8;   // from this many splits on, one workgroup per (sequence, head) merges
 
 int elems_per_lane(int dtype) { return dtype == MI355_F32 ? 4 : 8; }
@@ -419,8 +421,10 @@ constexpr int steps_for_group(int G) { return G >= 8 ? (kU > 2 ? 2 : kU) : kU; }
 // Launch geometry for a problem shape.  Deterministic in its arguments (plus the launch-plan
 // knobs, which only mi355_debug_set_knob changes after start-up), so the workspace query and the
 // launch agree.
+// spread_heads: the caller knows that a (block, kv head) tile is contiguous and large enough for
+// the ragged-batch plan below (the workspace query does not see strides and never sets it).
 int make_plan(int B, int Hq, int Hkv, int D, int block_size, int max_context, int dtype,
-              DecodePlan* plan, bool causal = false) {
+              DecodePlan* plan, bool causal = false, bool spread_heads = false) {
   if (B <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv) return fail(MI355_EINVAL, "bad B/Hq/Hkv (%d,%d,%d)", B, Hq, Hkv);
   if (dtype != MI355_F32 && dtype != MI355_BF16 && dtype != MI355_F16)
     return fail(MI355_EINVAL, "unknown dtype code %d", dtype);
@@ -455,12 +459,25 @@ int make_plan(int B, int Hq, int Hkv, int D, int block_size, int max_context, in
     while (pl.hpw > 1 && (int64_t)B * (Hkv / pl.hpw) * pl.qchunks < target &&
            ctx >= 2 * ts * (pl.nw / pl.hpw) * 2)  // every sub-range keeps >= 2 pipeline steps
       pl.hpw /= 2;
+    // Beyond filling the chip: fewer heads per workgroup still (its waves sharing a head's tokens)
+    // costs a uniform batch 0-1 % while every wave keeps a long enough stream (metric shape:
+    // 164.5 us with 256 workgroups of 8 heads, 164.6 with 2048 of one; head_dim 128 and fp32: +1 %)
+    // and evens out a ragged one, whose launch otherwise ends with the longest sequences'
+    // workgroups alone on the chip (contexts U[S/2, S]: 132 -> 128 us, U[1, S]: 104 -> 90 us,
+    // exponential lengths: 88 -> 54 us).  Only for caches whose (block, head) tiles are contiguous
+    // pieces of >= 2 KiB: with 1 KiB tiles (head_dim 32) it costs 7 %, and with rows of all heads
+    // interleaved ([block][row][head][d]) one head per workgroup reads 128-byte pieces (+15 %).
+    const int balance = spread_heads ? knob(kKnobPagedBalanceWgs) : 0;
+    while (pl.hpw > 1 && (int64_t)B * (Hkv / pl.hpw) * pl.qchunks < balance &&
+           ctx >= kBalanceSteps * ts * (pl.nw / pl.hpw) * 2)
+      pl.hpw /= 2;
   }
   pl.sub = pl.nw / pl.hpw;
   pl.hgroups = Hkv / pl.hpw;
   const int quantum = pl.sub * ts;  // tokens one workgroup consumes per pipeline step
   const int64_t base_wgs = (int64_t)B * pl.hgroups * pl.qchunks;
   int64_t want = ceil_div64(target, base_wgs);
+  const int fuse_up_to = knob(kKnobDecodeFusedMerge);
   const int64_t most = ctx / (2 * quantum) > 0 ? ctx / (2 * quantum) : 1;  // >= 2 steps per wave
   if (want > most) want = most;
   if (want < 1 || causal) want = 1;  // causal mode: one workgroup per query row, no token split
@@ -481,7 +498,6 @@ int make_plan(int B, int Hq, int Hkv, int D, int block_size, int max_context, in
   // themselves (decode_merge.h; arrival cells behind the partials): with the host queued ahead that saves 1-2 us of
   // 17-47 at 2-8 splits; from 16 splits on, the last workgroup's serial tail (arrival, then
   // reading every partial) takes longer than the wide merge kernel's launch.
-  const int fuse_up_to = knob(kKnobDecodeFusedMerge);
   pl.fused_merge = pl.nsplit > 1 && pl.nsplit <= (fuse_up_to < 65535 ? fuse_up_to : 65535) && !causal;
   if (pl.fused_merge) pl.ws_bytes += (size_t)B * pl.hgroups * pl.qchunks * sizeof(unsigned long long);
   *plan = pl;
@@ -693,6 +709,15 @@ int paged_decode_impl(const char* what, void* out, const void* q, int64_t q_stri
   if ((int64_t)max_context > (int64_t)max_blocks * block_size) max_context = max_blocks * block_size;
   DecodePlan pl;
   if (int rc = make_plan(B, Hq, Hkv, D, block_size, max_context, dtype, &pl)) return rc;
+  // The plan of the workspace query stands whenever it needs a workspace.  A launch without token
+  // splits may spread its kv heads over more workgroups instead (ragged batches, see make_plan),
+  // provided that plan needs no workspace either.
+  if (pl.nsplit == 1 && kv_stride_tok == D &&
+      (int64_t)block_size * D * (dtype == MI355_F32 ? 4 : 2) >= kSpreadTileBytes) {
+    DecodePlan spread;
+    if (make_plan(B, Hq, Hkv, D, block_size, max_context, dtype, &spread, false, true) == 0 && spread.nsplit == 1)
+      pl = spread;
+  }
   const int epl = elems_per_lane(dtype);
   if (kv_stride_block <= 0 || kv_stride_head < 0 || kv_stride_tok <= 0 || kv_stride_block >= (1LL << 31) ||
       kv_stride_tok >= (1LL << 31) || (int64_t)Hkv * kv_stride_head + D >= (1LL << 31))
