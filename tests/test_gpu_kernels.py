@@ -1087,6 +1087,33 @@ def test_token_splits_merged_in_the_launch_match_the_second_launch(ops, device, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('Hq,Hkv,D,B,S', [(8, 8, 64, 16, 8192), (32, 8, 128, 8, 8192), (8, 8, 64, 48, 3000)])
+def test_interleaved_layout_keeps_heads_together_for_large_launches(ops, device, Hq, Hkv, D, B, S):
+    """[block][row][head][d] caches: from 256 MiB of K/V on, the plan keeps enough kv heads in a
+    workgroup for 512-byte pieces per token and fills the chip with token splits instead (merged in
+    the launch).  Same numbers as the head-major layout gives for the same contents, ragged contexts."""
+    bs = 16
+    g = torch.Generator(device=device).manual_seed(Hq + D + B)
+    per = -(-S // bs)
+    nb = B * per + 3
+    kc = torch.randn((nb, Hkv, bs, D), generator=g, device=device).to(torch.bfloat16)
+    vc = torch.randn((nb, Hkv, bs, D), generator=g, device=device).to(torch.bfloat16)
+    bt = torch.randperm(nb, generator=g, device=device)[:B * per].view(B, per).to(torch.int32).contiguous()
+    q = torch.randn((B, Hq, D), generator=g, device=device).to(torch.bfloat16)
+    ctx = torch.randint(1, S + 1, (B,), generator=g, device=device).to(torch.int32)
+    ctx[0], ctx[1] = S, 0
+    want = ops.paged_decode(q, kc, vc, bt, ctx, S)
+    kc2, vc2 = kc.permute(0, 2, 1, 3).contiguous(), vc.permute(0, 2, 1, 3).contiguous()
+    for _ in range(3):
+        got = ops.paged_decode(q, kc2, vc2, bt, ctx, S, layout='NSHD')
+        torch.testing.assert_close(got.float(), want.float(), rtol=1.6e-2, atol=2e-3)
+    with ops.debug_knob('MI355_DECODE_FUSED_MERGE', 0):
+        two = ops.paged_decode(q, kc2, vc2, bt, ctx, S, layout='NSHD')
+    torch.testing.assert_close(two.float(), want.float(), rtol=1.6e-2, atol=2e-3)
+    assert not got[1].float().abs().sum().item()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('dtype,D,Hq,Hkv', [(torch.bfloat16, 64, 8, 8), (torch.float32, 64, 8, 8), (torch.bfloat16, 128, 32, 8),
                                             (torch.float16, 128, 4, 4)])
 def test_heads_spread_over_workgroups_match_the_plain_plan(ops, device, dtype, D, Hq, Hkv):
@@ -1094,7 +1121,7 @@ def test_heads_spread_over_workgroups_match_the_plain_plan(ops, device, dtype, D
     kv heads over up to MI355_PAGED_BALANCE_WGS workgroups (ragged batches finish together); the
     result equals the plain plan's (8 heads per workgroup) up to the order of the sub-range merge,
     for ragged contexts including empty and full ones, and the interleaved layout keeps the plain plan."""
-    bs, B, S = 16, 96, 2048
+    bs, B, S = 16, 128, 2048
     g = torch.Generator(device=device).manual_seed(D + Hq)
     per = S // bs
     nb = B * per + 5

@@ -421,10 +421,17 @@ constexpr int steps_for_group(int G) { return G >= 8 ? (kU > 2 ? 2 : kU) : kU; }
 // Launch geometry for a problem shape.  Deterministic in its arguments (plus the launch-plan
 // knobs, which only mi355_debug_set_knob changes after start-up), so the workspace query and the
 // launch agree.
-// spread_heads: the caller knows that a (block, kv head) tile is contiguous and large enough for
-// the ragged-batch plan below (the workspace query does not see strides and never sets it).
+// What the planner knows about the cache's strides (the workspace query knows nothing):
+//   kLayoutHeadTiles    a (block, kv head) tile is one contiguous piece of >= kSpreadTileBytes
+//                       ([block][head][row][d]): kv heads may be spread over workgroups (below)
+//   kLayoutInterleaved  the rows of all heads alternate ([block][row][head][d]): a workgroup of h
+//                       heads reads pieces of h * D elements per token
+enum PlanLayout { kLayoutUnknown = 0, kLayoutHeadTiles = 1, kLayoutInterleaved = 2 };
+constexpr int64_t kInterleavedPieceBytes = 512;        // smallest piece a bandwidth-bound launch should read ...
+constexpr int64_t kInterleavedBigBytes = 256ll << 20;  // ... from this many bytes of K/V on
+
 int make_plan(int B, int Hq, int Hkv, int D, int block_size, int max_context, int dtype,
-              DecodePlan* plan, bool causal = false, bool spread_heads = false) {
+              DecodePlan* plan, bool causal = false, int layout = kLayoutUnknown) {
   if (B <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv) return fail(MI355_EINVAL, "bad B/Hq/Hkv (%d,%d,%d)", B, Hq, Hkv);
   if (dtype != MI355_F32 && dtype != MI355_BF16 && dtype != MI355_F16)
     return fail(MI355_EINVAL, "unknown dtype code %d", dtype);
@@ -456,7 +463,16 @@ int make_plan(int B, int Hq, int Hkv, int D, int block_size, int max_context, in
   if (forced_hpw > 0 && forced_hpw <= pl.hpw && pl.hpw % forced_hpw == 0) {
     pl.hpw = forced_hpw;
   } else if (!causal) {
-    while (pl.hpw > 1 && (int64_t)B * (Hkv / pl.hpw) * pl.qchunks < target &&
+    // Interleaved rows, bandwidth-bound sizes: heads stay together until a token's piece is
+    // >= 512 bytes, and the chip is filled with token splits instead (merged in the launch).
+    // Measured, 8 kv heads: head_dim 64 B=16 ctx 8192: 52.0 us with one head per workgroup (128-byte
+    // pieces), 45.1 with four; B=16 ctx 32768: 188.8 -> 161.4; head_dim 128 (matrix-core kernel)
+    // B=16 ctx 32768: 334.8 -> 312.7 with two.  Small launches are latency-bound and keep the finer plan.
+    const int ebytes = dtype == MI355_F32 ? 4 : 2;
+    int min_hpw = 1;
+    if (layout == kLayoutInterleaved && (int64_t)B * ctx * Hkv * D * 2 * ebytes >= kInterleavedBigBytes)
+      while (min_hpw < pl.hpw && (int64_t)min_hpw * D * ebytes < kInterleavedPieceBytes) min_hpw *= 2;
+    while (pl.hpw > min_hpw && (int64_t)B * (Hkv / pl.hpw) * pl.qchunks < target &&
            ctx >= 2 * ts * (pl.nw / pl.hpw) * 2)  // every sub-range keeps >= 2 pipeline steps
       pl.hpw /= 2;
     // Beyond filling the chip: fewer heads per workgroup still (its waves sharing a head's tokens)
@@ -467,7 +483,7 @@ int make_plan(int B, int Hq, int Hkv, int D, int block_size, int max_context, in
     // exponential lengths: 88 -> 54 us).  Only for caches whose (block, head) tiles are contiguous
     // pieces of >= 2 KiB: with 1 KiB tiles (head_dim 32) it costs 7 %, and with rows of all heads
     // interleaved ([block][row][head][d]) one head per workgroup reads 128-byte pieces (+15 %).
-    const int balance = spread_heads ? knob(kKnobPagedBalanceWgs) : 0;
+    const int balance = layout == kLayoutHeadTiles ? knob(kKnobPagedBalanceWgs) : 0;
     while (pl.hpw > 1 && (int64_t)B * (Hkv / pl.hpw) * pl.qchunks < balance &&
            ctx >= kBalanceSteps * ts * (pl.nw / pl.hpw) * 2)
       pl.hpw /= 2;
@@ -670,14 +686,25 @@ int paged_prefill_rows(void* out, const void* q, int64_t q_stride_tok, const voi
 }  // namespace
 }  // namespace mi355
 
+namespace mi355 {
+namespace {
+// The launch picks its plan by the cache's strides, which the workspace query does not see: the
+// query answers for whichever plan needs more.
+size_t decode_workspace_bound(int B, int Hq, int Hkv, int D, int block_size, int max_context, int dtype) {
+  DecodePlan a, b;
+  if (make_plan(B, Hq, Hkv, D, block_size, max_context, dtype, &a)) return 0;
+  if (make_plan(B, Hq, Hkv, D, block_size, max_context, dtype, &b, false, kLayoutInterleaved)) return a.ws_bytes;
+  return a.ws_bytes > b.ws_bytes ? a.ws_bytes : b.ws_bytes;
+}
+}  // namespace
+}  // namespace mi355
+
 using namespace mi355;
 
 extern "C" size_t mi355_paged_decode_workspace_bytes(int32_t B, int32_t Hq, int32_t Hkv, int32_t D,
                                                      int32_t block_size, int32_t max_context,
                                                      int32_t dtype) {
-  DecodePlan pl;
-  if (make_plan(B, Hq, Hkv, D, block_size, max_context, dtype, &pl)) return 0;
-  return pl.ws_bytes;
+  return decode_workspace_bound(B, Hq, Hkv, D, block_size, max_context, dtype);
 }
 
 namespace mi355 {
@@ -708,14 +735,16 @@ int paged_decode_impl(const char* what, void* out, const void* q, int64_t q_stri
   if (max_blocks <= 0 || num_blocks <= 0) return fail(MI355_EINVAL, "%s: max_blocks/num_blocks", what);
   if ((int64_t)max_context > (int64_t)max_blocks * block_size) max_context = max_blocks * block_size;
   DecodePlan pl;
-  if (int rc = make_plan(B, Hq, Hkv, D, block_size, max_context, dtype, &pl)) return rc;
-  // The plan of the workspace query stands whenever it needs a workspace.  A launch without token
-  // splits may spread its kv heads over more workgroups instead (ragged batches, see make_plan),
-  // provided that plan needs no workspace either.
-  if (pl.nsplit == 1 && kv_stride_tok == D &&
-      (int64_t)block_size * D * (dtype == MI355_F32 ? 4 : 2) >= kSpreadTileBytes) {
+  const bool interleaved = kv_stride_tok != D;   // rows of one head are not adjacent
+  if (int rc = make_plan(B, Hq, Hkv, D, block_size, max_context, dtype, &pl, false,
+                         interleaved ? kLayoutInterleaved : kLayoutUnknown))
+    return rc;
+  // A launch without token splits over contiguous head tiles may spread its kv heads over more
+  // workgroups (ragged batches, see make_plan), provided that plan needs no workspace either.
+  if (!interleaved && pl.nsplit == 1 && (int64_t)block_size * D * (dtype == MI355_F32 ? 4 : 2) >= kSpreadTileBytes) {
     DecodePlan spread;
-    if (make_plan(B, Hq, Hkv, D, block_size, max_context, dtype, &spread, false, true) == 0 && spread.nsplit == 1)
+    if (make_plan(B, Hq, Hkv, D, block_size, max_context, dtype, &spread, false, kLayoutHeadTiles) == 0 &&
+        spread.nsplit == 1)
       pl = spread;
   }
   const int epl = elems_per_lane(dtype);
@@ -838,14 +867,15 @@ extern "C" int mi355_paged_decode_static(void* out, const void* q, int64_t q_str
   if (max_blocks > 0 && block_size > 0 && (int64_t)max_context > (int64_t)max_blocks * block_size)
     max_context = max_blocks * block_size;   // the plan is made for the clamped context, as in the body
   DecodePlan pl;
-  if (int rc = make_plan(B, Hq, Hkv, D, block_size, max_context, dtype, &pl)) return rc;
-  if (pl.ws_bytes > (size_t)MI355_STATIC_SCRATCH_BYTES)
+  if (int rc = make_plan(B, Hq, Hkv, D, block_size, max_context, dtype, &pl)) return rc;   // (argument errors)
+  const size_t need = decode_workspace_bound(B, Hq, Hkv, D, block_size, max_context, dtype);
+  if (need > (size_t)MI355_STATIC_SCRATCH_BYTES)
     return fail(MI355_EWORKSPACE,
                 "paged_decode_static: this shape needs %zu bytes of split-KV partials, the built-in scratch holds %zu; "
                 "use mi355_paged_decode with a caller workspace",
-                pl.ws_bytes, (size_t)MI355_STATIC_SCRATCH_BYTES);
+                need, (size_t)MI355_STATIC_SCRATCH_BYTES);
   void* ptr = nullptr;
-  if (pl.ws_bytes) {   // unsplit shapes never touch the array
+  if (need) {   // unsplit shapes never touch the array
     int rc = 0;
     ptr = static_scratch(&rc);
     if (!ptr) return rc;
