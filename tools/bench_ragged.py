@@ -1,6 +1,6 @@
 """Decode over ragged contexts at the metric shape against the launch plan's workgroup target, next
 to the uniform batch: what finer token splits (merged inside the launch) buy when lengths differ,
-and what they cost when they do not.   python tools/bench_ragged.py"""
+and what they cost when they do not.   python tools/bench_ragged.py [NHSD|NSHD]"""
 import os
 import sys
 
@@ -11,8 +11,12 @@ from bench import CONFIGS, build_inputs
 from mi355_paged import ops
 
 dev = torch.device('cuda', 0)
+LAYOUT = (sys.argv[1:] + ['NHSD'])[0]
 cfg = CONFIGS['metric']
 inp = build_inputs(cfg, dev, 0)
+if LAYOUT == 'NSHD':        # the same contents with the rows of all heads interleaved
+    inp['pools'] = [(kc.permute(0, 2, 1, 3).contiguous(), vc.permute(0, 2, 1, 3).contiguous(), bt)
+                    for kc, vc, bt in inp['pools']]
 B, S, H, D, BS = cfg['B'], cfg['S'], cfg['H'], cfg['D'], cfg['BS']
 out = torch.empty((B, H, D), dtype=torch.bfloat16, device=dev)
 g = torch.Generator(device=dev).manual_seed(1)
@@ -29,7 +33,7 @@ def run(ctx, n=60):
     def once():
         kc, vc, bt = inp['pools'][step[0] % 2]
         step[0] += 1
-        ops.paged_decode(inp['q'], kc, vc, bt, ctx, S, out=out)
+        ops.paged_decode(inp['q'], kc, vc, bt, ctx, S, out=out, layout=LAYOUT)
     for _ in range(5):
         once()
     torch.cuda._sleep(3_000_000)
