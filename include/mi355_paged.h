@@ -98,7 +98,9 @@ int mi355_paged_decode(void* out, const void* q, int64_t q_stride_seq,
                        float scale, int32_t dtype,
                        void* workspace, size_t workspace_bytes, void* stream);
 
-/* Scratch bytes mi355_paged_decode needs for this shape (split-KV partials and arrival counters). */
+/* Scratch bytes mi355_paged_decode needs for this shape (split-KV partials and arrival counters).
+ * The launch plan also depends on the cache's strides, which this query does not see: the answer
+ * covers whichever plan a launch of this shape may pick. */
 size_t mi355_paged_decode_workspace_bytes(int32_t B, int32_t Hq, int32_t Hkv, int32_t D,
                                           int32_t block_size, int32_t max_context, int32_t dtype);
 
