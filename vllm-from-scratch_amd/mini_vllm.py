@@ -534,8 +534,8 @@ class DeviceBlockTables:
                 self._uploaded[req.request_id] = len(table)
             out.append(row)
         if vals:
-            packed = _upload([r_idx, c_idx, vals], torch.int64, self.device)
-            self.tables[packed[0], packed[1]] = packed[2].to(torch.int32)
+            packed = _upload([r_idx, c_idx, vals], torch.int32, self.device)    # (int32 indexes are accepted as they are)
+            self.tables[packed[0], packed[1]] = packed[2]
         return out
 
     def release(self, request_id: str):
