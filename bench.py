@@ -19,9 +19,11 @@ One step = one decode step of one attention layer for the whole batch:
       exchanged, and every collective has completed, before the timed region closes.
 `value` = sequences (= tokens) decoded per second over all ranks; the timed region holds exactly
 --steps steps and no instrumentation.  `roofline` prices step (2), the dominant kernel, against
-HBM bandwidth: algorithmic bytes / the average of ROOFLINE_LAUNCHES launches, each between two
-HIP events on the launch stream, in a loop of the same steps that runs right after the timed
-region (so its size does not depend on --steps and its events cost the tokens/s figure nothing).
+HBM bandwidth: algorithmic bytes / the average launch duration by HIP events on the launch stream,
+taken right after the timed region (so its size does not depend on --steps and its events cost
+the tokens/s figure nothing): groups of 16 decode launches in a row between one event pair
+(`avg_launch_ms`), and, reported beside it, ROOFLINE_LAUNCHES launches inside full steps with an
+event pair each (`single_launch_brackets`, which also spans the event packets, about 2.3 us).
 `roofline.traffic` is the counter-measured HBM bytes per launch from the newest
 profiles/*_pmc_traffic.json, reported only when that file was collected with the very library
 this process loaded (sha256 match), else null with a `traffic_stale` note.  `cpu_baseline` times
@@ -117,6 +119,9 @@ def cpu_baseline(cfg, inp, budget_s=4.0, max_seqs=256):
 
 # Launches of the dominant kernel timed between HIP events after the tokens/s region.
 ROOFLINE_LAUNCHES = max(8, int(os.environ.get('BENCH_ROOFLINE_LAUNCHES', '64')))
+# ... and groups of launches in a row, one event pair per group (see the roofline loop)
+ROOFLINE_GROUP = 16
+ROOFLINE_GROUPS = max(4, int(os.environ.get('BENCH_ROOFLINE_GROUPS', '8')))
 
 
 def library_sha256():
@@ -256,7 +261,24 @@ def main():
         for j in range(ROOFLINE_LAUNCHES):
             step(args.steps + j, bracket=j)
         torch.cuda.synchronize()
-        kernel_ms = sorted(ev_a[j].elapsed_time(ev_b[j]) for j in range(ROOFLINE_LAUNCHES))
+        bracket_ms = sorted(ev_a[j].elapsed_time(ev_b[j]) for j in range(ROOFLINE_LAUNCHES))
+        # A pair of events around ONE launch also spans the two event packets themselves (about 2.3 us
+        # on this chip, whatever the kernel: the kernel trace of the same command is that much
+        # shorter), which is 1.4 % of the metric launch and 9 % of a 24 us one.  The launch duration
+        # the roofline uses therefore comes from ROOFLINE_GROUPS groups of ROOFLINE_GROUP decode
+        # launches in a row (KV pools rotating, nothing else between them), one event pair around
+        # each group: (kernel + dispatch gap) per launch, with the events' cost spread over the group.
+        g_a = [torch.cuda.Event(enable_timing=True) for _ in range(ROOFLINE_GROUPS)]
+        g_b = [torch.cuda.Event(enable_timing=True) for _ in range(ROOFLINE_GROUPS)]
+        torch.cuda._sleep(8_000_000)
+        for g in range(ROOFLINE_GROUPS):
+            g_a[g].record()
+            for j in range(ROOFLINE_GROUP):
+                kc, vc, bt = inp['pools'][(g * ROOFLINE_GROUP + j) % nsets]
+                ops.paged_decode(inp['q'], kc, vc, bt, inp['ctx'], S, layout='NHSD', out=out)
+            g_b[g].record()
+        torch.cuda.synchronize()
+        kernel_ms = sorted(g_a[g].elapsed_time(g_b[g]) / ROOFLINE_GROUP for g in range(ROOFLINE_GROUPS))
         avg_ms = sum(kernel_ms) / len(kernel_ms)
     if use_dist:
         dist.barrier()
@@ -285,11 +307,21 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "kernel": "mi355_paged_decode (paged_decode_kernel + split merge)",
                          "algorithmic_bytes_per_launch": abytes,
-                         "avg_launch_ms": round(avg_ms, 5), "launches_timed": len(kernel_ms),
+                         "avg_launch_ms": round(avg_ms, 5),
+                         "launches_timed": ROOFLINE_GROUPS * ROOFLINE_GROUP,
                          "p10_ms": round(kernel_ms[len(kernel_ms) // 10], 5),
                          "p50_ms": round(kernel_ms[len(kernel_ms) // 2], 5),
                          "p90_ms": round(kernel_ms[(len(kernel_ms) * 9) // 10], 5),
-                         "timing": "HIP events around each launch, in a loop of the same steps after the timed region"},
+                         "timing": f"HIP events around groups of {ROOFLINE_GROUP} launches in a row (pools rotating), "
+                                   f"{ROOFLINE_GROUPS} groups after the timed region; percentiles over groups",
+                         "single_launch_brackets": {
+                             "note": "one event pair per launch inside the same steps; includes the two event packets",
+                             "launches": len(bracket_ms),
+                             "avg_ms": round(sum(bracket_ms) / len(bracket_ms), 5),
+                             "p10_ms": round(bracket_ms[len(bracket_ms) // 10], 5),
+                             "p50_ms": round(bracket_ms[len(bracket_ms) // 2], 5),
+                             "p90_ms": round(bracket_ms[(len(bracket_ms) * 9) // 10], 5),
+                             "frac": round(abytes / (sum(bracket_ms) / len(bracket_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
             "library_sha256": lib_hash,
         }
         # HBM bytes per launch from the committed counter passes (tools/collect_profiles.sh +

@@ -251,6 +251,28 @@ __device__ __forceinline__ float cross_group(float v, Op op) {
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// Requests every 64-byte line of a kernel's argument block at once: the fields a prologue reads
+// one after the other (each read a dependent trip through the scalar cache when its line is cold)
+// then hit the cache.  Returns zero through an opaque register; adding it to a value the kernel
+// needs early (the thread index) keeps the requests at the top of the kernel.  The asm statement
+// is not volatile and touches no memory, so uniform loads after it stay scalar loads.
+template <int BYTES>
+__device__ __forceinline__ int warm_kernel_arguments() {
+  typedef const __attribute__((address_space(4))) uint32_t* karg_t;
+  karg_t ka = (karg_t)__builtin_amdgcn_kernarg_segment_ptr();
+  constexpr int kLines = (BYTES + 63) / 64;
+  static_assert(kLines <= 4, "argument block longer than 256 bytes");
+  uint32_t w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int line = i < kLines ? i : kLines - 1;
+    w[i] = ka[(line * 64 < BYTES - 4 ? line * 64 : BYTES - 4) / 4];
+  }
+  int zero;
+  asm("s_mov_b32 %0, 0" : "=s"(zero) : "s"(w[0]), "s"(w[1]), "s"(w[2]), "s"(w[3]));
+  return zero;
+}
+
 template <bool NT>
 __device__ __forceinline__ u32x4 load16(const void* p) {
   if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));

@@ -36,6 +36,10 @@ namespace {
 
 constexpr int kMaxThreads = 512;
 
+#ifndef MI355_DECODE_EARLY_BT
+#define MI355_DECODE_EARLY_BT 1
+#endif
+
 template <class Tag, int D>
 struct Geo {
   static constexpr int EPL = Tag::kEPL;      // elements per 16-byte lane load
@@ -57,19 +61,64 @@ __global__ void __launch_bounds__(kMaxThreads) paged_decode_kernel(const DecodeP
   float* s_part = reinterpret_cast<float*>(smem + p.lds_bt_bytes);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#if MI355_DECODE_EARLY_BT
+  int bid = blockIdx.x + warm_kernel_arguments<sizeof(DecodeParams)>();
+#else
   int bid = blockIdx.x;
+#endif
   const int qc = bid % p.qchunks;
   bid /= p.qchunks;
   const int hg = bid % p.hgroups;
   bid /= p.hgroups;
   const int sp = bid % p.nsplit;
   const int b = bid / p.nsplit;
+  const int t0 = sp * p.tps;
+  auto block_of = [&](int t) { return p.bs_shift >= 0 ? (t >> p.bs_shift) : (t / p.block_size); };
+  const int lb0 = block_of(t0);
+
+  // Decode mode: the first blockDim entries of this split's block-table slice are requested
+  // before the context length is known (the slice up to max_ctx always exists in the table, and
+  // ids are clamped before use), so the trips for the length, the table and q overlap instead of
+  // following each other.
+  int bt_first = 0;
+#if MI355_DECODE_EARLY_BT
+  if constexpr (!ROWS) {
+    // (no branch around the load, so that nothing waits for it here: packed causal launches, which
+    // have no table, read the first entry of their sequence offsets instead and ignore it)
+    const int end_max = min(p.max_ctx, t0 + p.tps);
+    const int nlb_max = end_max > t0 ? block_of(end_max - 1) - lb0 + 1 : 1;
+    const int32_t* src = p.cu ? p.cu : p.bt + ((int64_t)b * p.max_blocks + lb0 + min(tid, nlb_max - 1));
+    bt_first = *src;
+  }
+#endif
+
+  const int hslot = wave % p.hpw, sb = wave / p.hpw;
+  const int kvh = hg * p.hpw + hslot;
+  const int tl = lane / LPT, dg = lane % LPT;
+
+  // Query fragments: this lane's EPL dims of each of the G query heads.  Their loads are issued
+  // before the context length and the block table have arrived, so these trips to memory overlap
+  // (row groups first need their rows' offsets, read below).
+  int row0 = b, nrows = 1;             // ROWS: first q / out row of the group, rows in it
+  const int hq0 = ROWS ? kvh * p.gq + qc : kvh * p.gq + qc * G;
+  u32x4 qraw[G];
+  auto load_q = [&]() {
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi) {
+      const int hq = ROWS ? hq0 : (qc * G + gi < p.gq) ? hq0 + gi : hq0;
+      const int qrow = ROWS ? row0 + min(gi, nrows - 1) : b;
+      const char* src = static_cast<const char*>(p.q) +
+                        ((int64_t)qrow * p.q_stride_seq + (int64_t)hq * D + dg * EPL) * Tag::kBytes;
+      qraw[gi] = load16<false>(src);
+    }
+  };
+  if constexpr (!ROWS) load_q();
 
   // Causal mode (prompt processing): "sequence" b is query token b of a packed
   // batch; it attends to tokens start..b of its own prompt, which sit in k/v rows
   // start..b (block_size 1, physical id = token row).  No block table is read.
   int ctx, lin_start = 0;
-  int row0 = b, nrows = 1, ctx0 = 0;   // ROWS: first q / out row of the group, rows in it, context of the first
+  int ctx0 = 0;                        // ROWS: context of the group's first row
   int bt_row = b;                      // row of the block table this workgroup reads
   if constexpr (ROWS) {
     // packed prompts (p.cu): sequence `seq` owns rows cu[seq] .. cu[seq + 1] - 1 and starts at position 0;
@@ -103,7 +152,6 @@ __global__ void __launch_bounds__(kMaxThreads) paged_decode_kernel(const DecodeP
   } else {
     ctx = max(0, min(p.ctx[b], p.max_ctx));
   }
-  const int t0 = sp * p.tps;
   // Splits past the context do nothing and the merge skips them; with the merge in this launch
   // split 0 always takes part, so that an empty sequence still gets its (zero) output row.
   const bool fused = !ROWS && p.counters != nullptr;
@@ -111,29 +159,17 @@ __global__ void __launch_bounds__(kMaxThreads) paged_decode_kernel(const DecodeP
   if (fused && sp == 0 && tid == 0) tag_arrival_cell(p, b, hg, qc);
   const int wg_end = min(ctx, t0 + p.tps);
 
-  auto block_of = [&](int t) { return p.bs_shift >= 0 ? (t >> p.bs_shift) : (t / p.block_size); };
-
-  const int hslot = wave % p.hpw, sb = wave / p.hpw;
-  const int kvh = hg * p.hpw + hslot;
-  const int tl = lane / LPT, dg = lane % LPT;
-
-  // Query fragments: this lane's EPL dims of each of the G query heads.  Their loads are issued
-  // before the block table is staged, so both round trips to memory overlap.
-  const int hq0 = ROWS ? kvh * p.gq + qc : kvh * p.gq + qc * G;
-  u32x4 qraw[G];
-#pragma unroll
-  for (int gi = 0; gi < G; ++gi) {
-    const int hq = ROWS ? hq0 : (qc * G + gi < p.gq) ? hq0 + gi : hq0;
-    const int qrow = ROWS ? row0 + min(gi, nrows - 1) : b;
-    const char* src = static_cast<const char*>(p.q) +
-                      ((int64_t)qrow * p.q_stride_seq + (int64_t)hq * D + dg * EPL) * Tag::kBytes;
-    qraw[gi] = load16<false>(src);
-  }
+  if constexpr (ROWS) load_q();
 
   // Stage this split's slice of the block table in LDS (ids clamped for memory safety).
-  const int lb0 = block_of(t0);
   const int nlb = (wg_end > t0 && !p.cu) ? block_of(wg_end - 1) - lb0 + 1 : 0;
-  for (int i = tid; i < nlb; i += blockDim.x) {
+#if MI355_DECODE_EARLY_BT
+  constexpr bool kEarly = !ROWS;
+#else
+  constexpr bool kEarly = false;
+#endif
+  if (kEarly && tid < nlb) s_bt[tid] = min(max(bt_first, 0), p.num_blocks - 1);
+  for (int i = kEarly ? tid + (int)blockDim.x : tid; i < nlb; i += blockDim.x) {
     int id = p.bt[(int64_t)bt_row * p.max_blocks + lb0 + i];
     s_bt[i] = min(max(id, 0), p.num_blocks - 1);
   }
