@@ -124,6 +124,27 @@ ROOFLINE_GROUP = 16
 ROOFLINE_GROUPS = max(4, int(os.environ.get('BENCH_ROOFLINE_GROUPS', '8')))
 
 
+def measured_stream_bandwidth(device, reps=10):
+    """What this box's HBM delivers to plain streaming kernels, by HIP events: a device-to-device
+    copy of 1 GiB (bytes read + bytes written per second) and a read-only pass (a sum) over it."""
+    n = 1 << 28
+    src = torch.empty(n, dtype=torch.float32, device=device).normal_()
+    dst = torch.empty_like(src)
+    out = {}
+    for name, fn, nbytes in (("copy", lambda: dst.copy_(src), 2 * n * 4), ("read", lambda: src.sum(), n * 4)):
+        for _ in range(2):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        out[name] = nbytes * reps / (a.elapsed_time(b) * 1e-3) / 1e9
+    del src, dst
+    return out
+
+
 def library_sha256():
     from mi355_paged import _lib
     h = hashlib.sha256()
@@ -157,6 +178,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--config', default='metric', choices=sorted(CONFIGS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--strong', type=int, default=0, metavar='TOTAL',
+                    help='strong scaling: TOTAL sequences over all ranks (TOTAL / N per GPU, e.g. 2048) instead of '
+                         'the fixed per-GPU batch; reported as "scaling": "strong"')
     ap.add_argument('--gather-every', type=int, default=1,
                     help='steps whose sampled ids share one all-gather (N > 1; 1 = one collective per step, the '
                          'specified workload); every id is exchanged inside the timed region')
@@ -198,7 +222,11 @@ def main():
         faulthandler.dump_traceback_later(40, exit=False, file=sys.stderr)
     trace('process group up')
     from mi355_paged import dp, ops
-    cfg = CONFIGS[args.config]
+    cfg = dict(CONFIGS[args.config])
+    if args.strong:
+        if args.strong % world:
+            sys.exit(f"bench.py --strong {args.strong}: not a multiple of {world} ranks")
+        cfg['B'] = args.strong // world
     B, S, H, D, BS = cfg['B'], cfg['S'], cfg['H'], cfg['D'], cfg['BS']
     # small configs rotate through more pools so that a step never finds its KV in the 256 MiB Infinity Cache
     inp = build_inputs(cfg, device, seed=rank, sets=2 if args.config == 'metric' else 4)
@@ -289,12 +317,13 @@ def main():
         lib_hash = library_sha256()
         line = {
             "metric": "decode tokens/sec + achieved HBM GB/s, block_size=16 batch=256 seq=2048"
-                      if args.config == 'metric' else f"decode tokens/sec ({args.config})",
+                      if args.config == 'metric' and not args.strong else
+                      f"decode tokens/sec ({args.config}" + (f", {args.strong} sequences in total" if args.strong else "") + ")",
             "value": round(B * world * args.steps / elapsed, 1),
             "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"paged decode step: batch={B}/GPU, ctx={S}, heads={H}, head_dim={D}, "
                                    f"block_size={BS}, bf16 KV [blocks,heads,{BS},{D}], scattered block table; "
@@ -329,6 +358,11 @@ def main():
         traffic, note = measured_traffic(args.config, lib_hash)
         line["roofline"]["traffic"] = traffic
         line["roofline"].update(note)
+        # the same achieved figure against what this box's HBM gives plain streaming kernels
+        bw = measured_stream_bandwidth(device)
+        line["roofline"]["measured_on_this_box"] = {
+            "device_copy_1GiB_GBs": round(bw["copy"], 1), "read_only_sum_1GiB_GBs": round(bw["read"], 1),
+            "achieved_over_device_copy": round(achieved / bw["copy"], 4)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, inp)
         sys.stdout.flush()
