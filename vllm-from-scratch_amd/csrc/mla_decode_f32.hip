@@ -13,7 +13,10 @@
 // latent dims [w R/4, (w+1) R/4) -- as contraction dims of the scores AND as output dims, so it
 // reads only its own quarter of every cached row, straight from memory into the A-operand layout
 // (lane = token row, 16 bytes per lane per 16 dims) -- and an eighth of the rope pairs
-// (dims i and i + P/2 rotate together).  The four partial score tiles meet in LDS (one barrier
+// (dims i and i + P/2 rotate together): the lane quarter g holds a run of consecutive rope dims --
+// g = 0, 1 from the low half, g = 2, 3 their partners from the high half -- fetched, like their
+// cos / sin entries, in 16-byte pieces when the rows are aligned (VEC), and lanes g and g ^ 2
+// trade their values for the rotation.  The four partial score tiles meet in LDS (one barrier
 // per tile, two buffers); every wave then holds the full 16 x 16 scores with the head on the lane
 // and four tokens in its registers: register r is, unchanged, the B operand of the instruction
 // that contracts tokens {r, 4 + r, 8 + r, 12 + r}.  The A operand of that product is the wave's
@@ -50,14 +53,35 @@ __device__ __forceinline__ f32x4v mma4(float a, float b, f32x4v c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-template <int R, int P, int WAVES>
+// RS consecutive floats: 16-byte pieces (or one 8-byte piece) when VEC, else element by element.
+template <int RS, bool VEC>
+__device__ __forceinline__ void load_run(const float* src, float (&dst)[RS]) {
+  if constexpr (VEC && RS % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < RS / 4; ++i) {
+      const f32x4v v = *reinterpret_cast<const f32x4v*>(src + 4 * i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dst[4 * i + e] = v[e];
+    }
+  } else if constexpr (VEC && RS == 2) {
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    const f32x2v v = *reinterpret_cast<const f32x2v*>(src);
+    dst[0] = v[0];
+    dst[1] = v[1];
+  } else {
+#pragma unroll
+    for (int e = 0; e < RS; ++e) dst[e] = src[e];
+  }
+}
+
+template <int R, int P, int WAVES, bool VEC>
 __global__ void __launch_bounds__(WAVES * 64) mla_decode_f32_kernel(const MlaF32Params p) {
   constexpr int Q = R / WAVES;            // latent dims per wave
   constexpr int NJ = Q / 16;              // 16-dim groups per wave
   constexpr int PR = P / (2 * WAVES);     // rope dims per wave in each half
-  constexpr int RS = 2 * PR / 4;          // rope contraction steps per wave
+  constexpr int RS = 2 * PR / 4;          // rope dims per lane quarter = rope contraction steps per wave
   constexpr int PITCH = Q + 4;            // words per token row of the transposed-read image
-  static_assert(Q % 16 == 0 && PR >= 2 && (2 * PR) % 4 == 0, "shape");
+  static_assert(Q % 16 == 0 && PR >= 2 && PR == 2 * RS, "shape");
   __shared__ __attribute__((aligned(16))) float s_part[WAVES > 1 ? 2 : 1][WAVES][256];
   __shared__ __attribute__((aligned(16))) float s_v[WAVES][16 * PITCH];
 
@@ -74,17 +98,11 @@ __global__ void __launch_bounds__(WAVES * 64) mla_decode_f32_kernel(const MlaF32
   const int ctx = min(ctx_all, tok0 + p.tps);
   const int head = ht * 16 + c, head_c = min(head, p.H - 1);
 
-  // rope dims of this wave: step s, slot g -> index 4 s + g into [lo dims | hi dims]
-  int rdim[RS], rpair[RS];
-  float rsign[RS];
-#pragma unroll
-  for (int s = 0; s < RS; ++s) {
-    const int idx = 4 * s + g;
-    const bool lo = idx < PR;
-    rdim[s] = lo ? PR * wave + idx : P / 2 + PR * wave + (idx - PR);
-    rpair[s] = lo ? rdim[s] + P / 2 : rdim[s] - P / 2;
-    rsign[s] = lo ? -1.f : 1.f;
-  }
+  // rope dims of this lane: rbase .. rbase + RS - 1 (step s of the contraction takes dim rbase + s);
+  // lane quarter g ^ 2 holds their rotation partners
+  const bool rlo = g < 2;
+  const int rbase = (rlo ? 0 : P / 2) + PR * wave + (g & 1) * RS;
+  const float rsign = rlo ? -1.f : 1.f;
 
   // query fragments (B operands): lane (c = head, g) holds q[head][Q w + 16 j + 4 g + e] and the rope dims above
   const float* qrow = p.q + (int64_t)row * p.q_stride_row + (int64_t)head_c * (R + P);
@@ -92,8 +110,7 @@ __global__ void __launch_bounds__(WAVES * 64) mla_decode_f32_kernel(const MlaF32
   float qr[RS];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) ql[j] = *reinterpret_cast<const f32x4v*>(qrow + Q * wave + 16 * j + 4 * g);
-#pragma unroll
-  for (int s = 0; s < RS; ++s) qr[s] = qrow[R + rdim[s]];
+  load_run<RS, VEC>(qrow + R + rbase, qr);
 
   f32x4v o[NJ];
 #pragma unroll
@@ -105,37 +122,45 @@ __global__ void __launch_bounds__(WAVES * 64) mla_decode_f32_kernel(const MlaF32
 
   // A tile's loads: this lane's token row (clamped to the context; rows past it are masked below)
   f32x4v kk[NJ], kk_n[NJ];
-  float rv[RS], rp[RS], rc[RS], rn[RS], rv_n[RS], rp_n[RS], rc_n[RS], rn_n[RS];
-  auto load_tile = [&](int t0, f32x4v (&k4)[NJ], float (&v)[RS], float (&pv)[RS], float (&cs)[RS], float (&sn)[RS]) {
+  float rv[RS], rc[RS], rn[RS], rv_n[RS], rc_n[RS], rn_n[RS];
+  auto load_tile = [&](int t0, f32x4v (&k4)[NJ], float (&v)[RS], float (&cs)[RS], float (&sn)[RS]) {
     const int key = min(t0 + c, max(ctx - 1, 0));           // (t0 counts from token 0 of the sequence)
     const float* krow = ckv_seq + (int64_t)key * p.ckv_stride_tok;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) k4[j] = *reinterpret_cast<const f32x4v*>(krow + 16 * j + 4 * g);
     const float* rrow = kr_seq + (int64_t)key * p.krope_stride_tok;
     const int trow = min(key, p.table_len - 1) * P;
-#pragma unroll
-    for (int s = 0; s < RS; ++s) {
-      v[s] = rrow[rdim[s]];
-      pv[s] = rrow[rpair[s]];
-      cs[s] = p.cos_t[trow + rdim[s]];
-      sn[s] = p.sin_t[trow + rdim[s]];
-    }
+    load_run<RS, VEC>(rrow + rbase, v);
+    load_run<RS, VEC>(p.cos_t + trow + rbase, cs);
+    load_run<RS, VEC>(p.sin_t + trow + rbase, sn);
   };
 
   const int ntiles = ctx > tok0 ? (ctx - tok0 + 15) / 16 : 0;
-  if (ntiles > 0) load_tile(tok0, kk, rv, rp, rc, rn);
+  if (ntiles > 0) load_tile(tok0, kk, rv, rc, rn);
   float* my_v = s_v[wave];
   for (int t = 0; t < ntiles; ++t) {
     const int t0 = tok0 + t * 16;
-    if (t + 1 < ntiles) load_tile(t0 + 16, kk_n, rv_n, rp_n, rc_n, rn_n);
-    // ---- this wave's share of the scores: 16 tokens x 16 heads over its latent quarter and rope dims
-    f32x4v sp = {0.f, 0.f, 0.f, 0.f};
+    if (t + 1 < ntiles) load_tile(t0 + 16, kk_n, rv_n, rc_n, rn_n);
+    // ---- this wave's share of the scores: 16 tokens x 16 heads over its latent quarter and rope dims,
+    // on two accumulators (one chain of dependent matrix instructions would run at their latency, not
+    // at their issue rate)
+    f32x4v sp = {0.f, 0.f, 0.f, 0.f}, sp2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+    for (int j = 0; j < NJ; j += 2) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) sp = mma4(kk[j][e], ql[j][e], sp);
+      for (int e = 0; e < 4; ++e) {
+        sp = mma4(kk[j][e], ql[j][e], sp);
+        if (j + 1 < NJ) sp2 = mma4(kk[j + 1][e], ql[j + 1][e], sp2);
+      }
+    }
 #pragma unroll
-    for (int s = 0; s < RS; ++s) sp = mma4(__builtin_fmaf(rsign[s] * rp[s], rn[s], rv[s] * rc[s]), qr[s], sp);
+    for (int s = 0; s < RS; ++s) {
+      const float partner = __shfl_xor(rv[s], 32);     // the same token's dim rbase + s -+ P/2
+      const float roped = __builtin_fmaf(rsign * partner, rn[s], rv[s] * rc[s]);
+      if (s & 1) sp2 = mma4(roped, qr[s], sp2);
+      else sp = mma4(roped, qr[s], sp);
+    }
+    sp += sp2;
     // the quarter tile, row-major, for the transposed reads of the value product
 #pragma unroll
     for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x4v*>(my_v + c * PITCH + 16 * j + 4 * g) = kk[j];
@@ -181,7 +206,6 @@ __global__ void __launch_bounds__(WAVES * 64) mla_decode_f32_kernel(const MlaF32
 #pragma unroll
       for (int s = 0; s < RS; ++s) {
         rv[s] = rv_n[s];
-        rp[s] = rp_n[s];
         rc[s] = rc_n[s];
         rn[s] = rn_n[s];
       }
@@ -208,20 +232,27 @@ __global__ void __launch_bounds__(WAVES * 64) mla_decode_f32_kernel(const MlaF32
   }
 }
 
+template <int R, int P, int WAVES>
+void launch_rp(const MlaF32Params& p, dim3 g, bool vec, hipStream_t s) {
+  if (vec) hipLaunchKernelGGL((mla_decode_f32_kernel<R, P, WAVES, true>), g, dim3(WAVES * 64), 0, s, p);
+  else hipLaunchKernelGGL((mla_decode_f32_kernel<R, P, WAVES, false>), g, dim3(WAVES * 64), 0, s, p);
+}
+
+// vec: rope rows, q's rope part and the cos / sin tables may be read in 16-byte pieces
 template <int R>
-int launch_r(const MlaF32Params& p, int P, hipStream_t s) {
+int launch_r(const MlaF32Params& p, int P, bool vec, hipStream_t s) {
   const int64_t grid = (int64_t)p.rows * p.nsplit * p.n_ht;
   if (grid >= (1LL << 31)) return fail(MI355_EINVAL, "mla_decode (fp32): grid too large");
   const dim3 g((unsigned)grid);
   if constexpr (R >= 256) {
-    if (P == 32) hipLaunchKernelGGL((mla_decode_f32_kernel<R, 32, 4>), g, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((mla_decode_f32_kernel<R, 64, 4>), g, dim3(256), 0, s, p);
+    if (P == 32) launch_rp<R, 32, 4>(p, g, vec, s);
+    else launch_rp<R, 64, 4>(p, g, vec, s);
   } else {
     switch (P) {
-      case 8: hipLaunchKernelGGL((mla_decode_f32_kernel<R, 8, 1>), g, dim3(64), 0, s, p); break;
-      case 16: hipLaunchKernelGGL((mla_decode_f32_kernel<R, 16, 1>), g, dim3(64), 0, s, p); break;
-      case 32: hipLaunchKernelGGL((mla_decode_f32_kernel<R, 32, 1>), g, dim3(64), 0, s, p); break;
-      default: hipLaunchKernelGGL((mla_decode_f32_kernel<R, 64, 1>), g, dim3(64), 0, s, p); break;
+      case 8: launch_rp<R, 8, 1>(p, g, vec, s); break;
+      case 16: launch_rp<R, 16, 1>(p, g, vec, s); break;
+      case 32: launch_rp<R, 32, 1>(p, g, vec, s); break;
+      default: launch_rp<R, 64, 1>(p, g, vec, s); break;
     }
   }
   if (int rc = check_launch("mla_decode_f32_kernel")) return rc;
@@ -283,12 +314,15 @@ int mla_f32_launch(float* out, const float* q, int64_t q_stride_row, const float
   p.table_len = table_len;
   p.max_ctx = max_context;
   p.scale_log2e = scale * 1.4426950408889634f;
+  // (q rows are 16-byte aligned by the caller's checks and R is a multiple of 4, so q's rope part is too)
+  const bool vec = !(((uintptr_t)k_rope | (uintptr_t)cos_table | (uintptr_t)sin_table) & 15) &&
+                   krope_stride_tok % 4 == 0 && krope_stride_seq % 4 == 0;
   switch (R) {
-    case 32: return launch_r<32>(p, P, stream);
-    case 64: return launch_r<64>(p, P, stream);
-    case 128: return launch_r<128>(p, P, stream);
-    case 256: return launch_r<256>(p, P, stream);
-    case 512: return launch_r<512>(p, P, stream);
+    case 32: return launch_r<32>(p, P, vec, stream);
+    case 64: return launch_r<64>(p, P, vec, stream);
+    case 128: return launch_r<128>(p, P, vec, stream);
+    case 256: return launch_r<256>(p, P, vec, stream);
+    case 512: return launch_r<512>(p, P, vec, stream);
   }
   return fail(MI355_EUNSUPPORTED, "mla_decode (fp32): kv_lora_rank %d", R);
 }
