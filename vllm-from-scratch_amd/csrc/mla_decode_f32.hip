@@ -53,6 +53,39 @@ __device__ __forceinline__ f32x4v mma4(float a, float b, f32x4v c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// The value of x in both 16-lane rows of a row pair (rows 0|1 and 2|3) / in both halves of the wave:
+// one v_permlane16_swap / v_permlane32_swap (it exchanges the odd rows [upper half] of its first
+// register with the even rows [lower half] of its second), in the vector ALU instead of a trip
+// through the LDS crossbar.  Written as asm because this compiler's builtins return the first
+// result for both; the s_nop covers the wait states after a vector write of the operands.
+__device__ __forceinline__ void row_pair_values(float x, float& even_row, float& odd_row) {
+  float a = x, b = x;
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  even_row = a;
+  odd_row = b;
+}
+__device__ __forceinline__ void half_values(float x, float& lower, float& upper) {
+  float a = x, b = x;
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  lower = a;
+  upper = b;
+}
+// Reductions over the four lanes c, c + 16, c + 32, c + 48 (fixed order: results repeat run to run).
+__device__ __forceinline__ float quarters_max(float x) {
+  float a, b;
+  row_pair_values(x, a, b);
+  x = fmaxf(a, b);
+  half_values(x, a, b);
+  return fmaxf(a, b);
+}
+__device__ __forceinline__ float quarters_sum(float x) {
+  float a, b;
+  row_pair_values(x, a, b);
+  x = a + b;
+  half_values(x, a, b);
+  return a + b;
+}
+
 // RS consecutive floats: 16-byte pieces (or one 8-byte piece) when VEC, else element by element.
 template <int RS, bool VEC>
 __device__ __forceinline__ void load_run(const float* src, float (&dst)[RS]) {
@@ -75,14 +108,14 @@ __device__ __forceinline__ void load_run(const float* src, float (&dst)[RS]) {
 }
 
 template <int R, int P, int WAVES, bool VEC>
-__global__ void __launch_bounds__(WAVES * 64) mla_decode_f32_kernel(const MlaF32Params p) {
+__global__ void __launch_bounds__(WAVES * 64, 2) mla_decode_f32_kernel(const MlaF32Params p) {
   constexpr int Q = R / WAVES;            // latent dims per wave
   constexpr int NJ = Q / 16;              // 16-dim groups per wave
   constexpr int PR = P / (2 * WAVES);     // rope dims per wave in each half
   constexpr int RS = 2 * PR / 4;          // rope dims per lane quarter = rope contraction steps per wave
   constexpr int PITCH = Q + 4;            // words per token row of the transposed-read image
   static_assert(Q % 16 == 0 && PR >= 2 && PR == 2 * RS, "shape");
-  __shared__ __attribute__((aligned(16))) float s_part[WAVES > 1 ? 2 : 1][WAVES][256];
+  __shared__ __attribute__((aligned(16))) float s_part[2][WAVES][WAVES > 1 ? 256 : 4];   // (unused by one wave)
   __shared__ __attribute__((aligned(16))) float s_v[WAVES][16 * PITCH];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -120,58 +153,79 @@ __global__ void __launch_bounds__(WAVES * 64) mla_decode_f32_kernel(const MlaF32
   const float* ckv_seq = p.ckv + (int64_t)seq * p.ckv_stride_seq + Q * wave;
   const float* kr_seq = p.krope + (int64_t)seq * p.krope_stride_seq;
 
-  // A tile's loads: this lane's token row (clamped to the context; rows past it are masked below)
-  f32x4v kk[NJ], kk_n[NJ];
-  float rv[RS], rc[RS], rn[RS], rv_n[RS], rc_n[RS], rn_n[RS];
-  auto load_tile = [&](int t0, f32x4v (&k4)[NJ], float (&v)[RS], float (&cs)[RS], float (&sn)[RS]) {
+  // A tile in registers: this lane's token row (clamped to the context; rows past it are masked below)
+  struct Tile {
+    f32x4v k[NJ];
+    float v[RS], cs[RS], sn[RS];
+  };
+  auto load_tile = [&](int t0, Tile& x) __attribute__((always_inline)) {
     const int key = min(t0 + c, max(ctx - 1, 0));           // (t0 counts from token 0 of the sequence)
     const float* krow = ckv_seq + (int64_t)key * p.ckv_stride_tok;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) k4[j] = *reinterpret_cast<const f32x4v*>(krow + 16 * j + 4 * g);
+    for (int j = 0; j < NJ; ++j) x.k[j] = *reinterpret_cast<const f32x4v*>(krow + 16 * j + 4 * g);
     const float* rrow = kr_seq + (int64_t)key * p.krope_stride_tok;
     const int trow = min(key, p.table_len - 1) * P;
-    load_run<RS, VEC>(rrow + rbase, v);
-    load_run<RS, VEC>(p.cos_t + trow + rbase, cs);
-    load_run<RS, VEC>(p.sin_t + trow + rbase, sn);
+    load_run<RS, VEC>(rrow + rbase, x.v);
+    load_run<RS, VEC>(p.cos_t + trow + rbase, x.cs);
+    load_run<RS, VEC>(p.sin_t + trow + rbase, x.sn);
   };
 
   const int ntiles = ctx > tok0 ? (ctx - tok0 + 15) / 16 : 0;
-  if (ntiles > 0) load_tile(tok0, kk, rv, rc, rn);
   float* my_v = s_v[wave];
-  for (int t = 0; t < ntiles; ++t) {
-    const int t0 = tok0 + t * 16;
-    if (t + 1 < ntiles) load_tile(t0 + 16, kk_n, rv_n, rc_n, rn_n);
-    // ---- this wave's share of the scores: 16 tokens x 16 heads over its latent quarter and rope dims,
-    // on two accumulators (one chain of dependent matrix instructions would run at their latency, not
-    // at their issue rate)
+  f32x4v sc_ahead = {0.f, 0.f, 0.f, 0.f};    // one wave: the scores computed one tile ahead stay in registers
+
+  // This wave's share of a tile's scores: 16 tokens x 16 heads over its latent quarter and rope
+  // dims, on two accumulators (one chain of dependent matrix instructions would run at their
+  // latency, not at their issue rate).  Four waves: the share goes to the tile's exchange buffer.
+  auto scores = [&](int t, const Tile& x) __attribute__((always_inline)) {
     f32x4v sp = {0.f, 0.f, 0.f, 0.f}, sp2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < NJ; j += 2) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        sp = mma4(kk[j][e], ql[j][e], sp);
-        if (j + 1 < NJ) sp2 = mma4(kk[j + 1][e], ql[j + 1][e], sp2);
+        sp = mma4(x.k[j][e], ql[j][e], sp);
+        if (j + 1 < NJ) sp2 = mma4(x.k[j + 1][e], ql[j + 1][e], sp2);
       }
     }
 #pragma unroll
     for (int s = 0; s < RS; ++s) {
-      const float partner = __shfl_xor(rv[s], 32);     // the same token's dim rbase + s -+ P/2
-      const float roped = __builtin_fmaf(rsign * partner, rn[s], rv[s] * rc[s]);
+      float lower, upper;
+      half_values(x.v[s], lower, upper);
+      const float partner = rlo ? upper : lower;       // the same token's dim rbase + s -+ P/2
+      const float roped = __builtin_fmaf(rsign * partner, x.sn[s], x.v[s] * x.cs[s]);
       if (s & 1) sp2 = mma4(roped, qr[s], sp2);
       else sp = mma4(roped, qr[s], sp);
     }
     sp += sp2;
-    // the quarter tile, row-major, for the transposed reads of the value product
+    if constexpr (WAVES > 1) *reinterpret_cast<f32x4v*>(&s_part[t & 1][wave][lane * 4]) = sp;
+    else sc_ahead = sp;
+  };
+  // a quarter tile, row-major, for the transposed reads of the value product
+  auto stash = [&](const Tile& x) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x4v*>(my_v + c * PITCH + 16 * j + 4 * g) = kk[j];
-    f32x4v sc = sp;
+    for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x4v*>(my_v + c * PITCH + 16 * j + 4 * g) = x.k[j];
+  };
+
+  // Software pipeline: the scores of tile t + 1 are issued before the softmax and the value product
+  // of tile t, so the exchange of a tile's partial scores (LDS write, barrier, LDS reads) has a whole
+  // value product between its two ends, and after every barrier a wave has matrix work ready.
+  // Entering step t: `ready` = tile t + 1, the other register tile = tile t + 2 (in flight), my_v =
+  // tile t, exchange buffer t & 1 = the partial scores of tile t (behind a barrier).  At its end the
+  // step refills `ready` with tile t + 3, and the two register tiles swap roles: a tile's loads have
+  // a whole step before they are waited for, and nothing is copied (with a copy at the loop's back
+  // edge the compiler loads into temporaries and waits for the loads it has just issued).
+  // A step has no branches: tiles past the last one are loaded (their rows clamp to the last token),
+  // scored and stashed like the others; a step on such a tile sees every token masked and adds
+  // nothing, which lets the loop run in pairs of steps.
+  auto step = [&](int t, Tile& ready) __attribute__((always_inline)) {
+    const int t0 = tok0 + t * 16;
+    f32x4v sc = sc_ahead;
     if constexpr (WAVES > 1) {
-      *reinterpret_cast<f32x4v*>(&s_part[t & 1][wave][lane * 4]) = sp;
-      __syncthreads();
       sc = *reinterpret_cast<const f32x4v*>(&s_part[t & 1][0][lane * 4]);
 #pragma unroll
       for (int w = 1; w < WAVES; ++w) sc += *reinterpret_cast<const f32x4v*>(&s_part[t & 1][w][lane * 4]);
     }
+    scores(t + 1, ready);
     // ---- online softmax; lane (c, g) holds tokens t0 + 4 g + r of head c
     float v[4], mx = -__builtin_inff();
 #pragma unroll
@@ -179,8 +233,7 @@ __global__ void __launch_bounds__(WAVES * 64) mla_decode_f32_kernel(const MlaF32
       v[r] = (t0 + 4 * g + r < ctx) ? sc[r] * p.scale_log2e : -__builtin_inff();
       mx = fmaxf(mx, v[r]);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    mx = quarters_max(mx);
     const float m_new = fmaxf(m_run, mx);
     const float f = fast_exp2(m_run - m_new);
     m_run = m_new;
@@ -190,25 +243,51 @@ __global__ void __launch_bounds__(WAVES * 64) mla_decode_f32_kernel(const MlaF32
       pr[r] = fast_exp2(v[r] - m_new);
       ps += pr[r];
     }
-    ps += __shfl_xor(ps, 16);
-    ps += __shfl_xor(ps, 32);
+    ps = quarters_sum(ps);
     l_run = l_run * f + ps;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) o[j] *= f;
-    // ---- out^T += V^T . P^T over this wave's latent quarter
+    // ---- out^T += V^T . P^T over this wave's latent quarter.  The A operands come from the LDS
+    // image kVAhead matrix instructions ahead of their use and the order is pinned: left alone, the
+    // compiler reads two values into the same registers, waits, issues their two instructions, and
+    // so on -- every pair of matrix instructions behind a full LDS round trip.
+    {
+      constexpr int NV = 4 * NJ, kVAhead = NV < 8 ? NV : 8;
+      auto a_at = [&](int n) __attribute__((always_inline)) {
+        return my_v[(4 * g + n / NJ) * PITCH + 16 * (n % NJ) + c];
+      };
+      float abuf[kVAhead];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+      for (int n = 0; n < kVAhead; ++n) abuf[n] = a_at(n);
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) o[j] = mma4(my_v[(4 * g + r) * PITCH + 16 * j + c], pr[r], o[j]);
-    if (t + 1 < ntiles) {
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) kk[j] = kk_n[j];
-#pragma unroll
-      for (int s = 0; s < RS; ++s) {
-        rv[s] = rv_n[s];
-        rc[s] = rc_n[s];
-        rn[s] = rn_n[s];
+      for (int n = 0; n < NV; ++n) {
+        const float a = abuf[n % kVAhead];
+        if (n + kVAhead < NV) abuf[n % kVAhead] = a_at(n + kVAhead);
+        o[n % NJ] = mma4(a, pr[n / NJ], o[n % NJ]);
       }
+      __builtin_amdgcn_sched_group_barrier(0x100, kVAhead, 0);
+#pragma unroll
+      for (int n = 0; n < NV - kVAhead; ++n) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, kVAhead, 0);
+    }
+    stash(ready);                      // tile t + 1 (after this wave's reads of tile t: LDS runs a wave's accesses in order)
+    load_tile(t0 + 48, ready);         // tile t + 3
+    if constexpr (WAVES > 1) __syncthreads();
+  };
+  if (ntiles > 0) {
+    Tile ta, tb;
+    load_tile(tok0, tb);
+    load_tile(tok0 + 16, ta);
+    scores(0, tb);
+    stash(tb);
+    load_tile(tok0 + 32, tb);
+    if constexpr (WAVES > 1) __syncthreads();
+    for (int t = 0; t < ntiles; t += 2) {
+      step(t, ta);
+      step(t + 1, tb);
     }
   }
 
