@@ -256,10 +256,11 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // then hit the cache.  Returns zero through an opaque register; adding it to a value the kernel
 // needs early (the thread index) keeps the requests at the top of the kernel.  The asm statement
 // is not volatile and touches no memory, so uniform loads after it stay scalar loads.
-template <int BYTES>
+// OFFSET: where the block starts within the kernel's arguments (scalar arguments before it).
+template <int BYTES, int OFFSET = 0>
 __device__ __forceinline__ int warm_kernel_arguments() {
   typedef const __attribute__((address_space(4))) uint32_t* karg_t;
-  karg_t ka = (karg_t)__builtin_amdgcn_kernarg_segment_ptr();
+  karg_t ka = (karg_t)__builtin_amdgcn_kernarg_segment_ptr() + OFFSET / 4;
   constexpr int kLines = (BYTES + 63) / 64;
   static_assert(kLines <= 4, "argument block longer than 256 bytes");
   uint32_t w[4];

@@ -35,9 +35,13 @@ namespace mi355 {
 namespace {
 
 constexpr int kMaxThreads = 512;
+constexpr int kLeadBytes = 64;   // the decode kernel's leading scalar arguments (16 dwords, before DecodeParams)
 
 #ifndef MI355_DECODE_EARLY_BT
 #define MI355_DECODE_EARLY_BT 1
+#endif
+#ifndef MI355_DECODE_WARM
+#define MI355_DECODE_WARM 1
 #endif
 
 template <class Tag, int D>
@@ -52,8 +56,23 @@ struct Geo {
 // one query head instead of G query heads of one row.  They share every K/V load -- row r reads
 // keys 0..r, so the group streams keys 0..last row once and masks, per slot, the few keys past
 // that slot's own position -- which divides the K/V traffic of prompt processing by G.
+// The fields a decode launch needs before its first loads, as leading scalar arguments: the first
+// 16 dwords of a kernel's arguments arrive in SGPRs with the wave (kernel-argument preload), so the
+// requests for the context length, the block-table slice and q go out without a first trip to the
+// argument block.  The same values are in DecodeParams; everything after the prologue reads those.
+struct DecodeLead {
+  const int32_t* bt;
+  const int32_t* ctx;    // null: packed causal launch (no table, no context lengths)
+  const void* q;
+  int q_stride_seq;      // (host: < 2^31)
+  int qchunks, hgroups, nsplit, tps, bs_shift, max_blocks, max_ctx, hpw, gq;
+};
+
 template <class Tag, int D, int G, int U, bool NT, bool ROWS = false>
-__global__ void __launch_bounds__(kMaxThreads) paged_decode_kernel(const DecodeParams p) {
+__global__ void __launch_bounds__(kMaxThreads)
+paged_decode_kernel(const int32_t* a_bt, const int32_t* a_ctx, const void* a_q, int a_q_stride_seq, int a_qchunks,
+                    int a_hgroups, int a_nsplit, int a_tps, int a_bs_shift, int a_max_blocks, int a_max_ctx,
+                    int a_hpw, int a_gq, const DecodeParams p) {
   constexpr int EPL = Geo<Tag, D>::EPL, LPT = Geo<Tag, D>::LPT, TPL = Geo<Tag, D>::TPL;
   constexpr int TS = TPL * U;  // tokens per pipeline step of one wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -61,19 +80,19 @@ __global__ void __launch_bounds__(kMaxThreads) paged_decode_kernel(const DecodeP
   float* s_part = reinterpret_cast<float*>(smem + p.lds_bt_bytes);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#if MI355_DECODE_EARLY_BT
-  int bid = blockIdx.x + warm_kernel_arguments<sizeof(DecodeParams)>();
+#if MI355_DECODE_EARLY_BT && MI355_DECODE_WARM
+  int bid = blockIdx.x + warm_kernel_arguments<sizeof(DecodeParams), kLeadBytes>();
 #else
   int bid = blockIdx.x;
 #endif
-  const int qc = bid % p.qchunks;
-  bid /= p.qchunks;
-  const int hg = bid % p.hgroups;
-  bid /= p.hgroups;
-  const int sp = bid % p.nsplit;
-  const int b = bid / p.nsplit;
-  const int t0 = sp * p.tps;
-  auto block_of = [&](int t) { return p.bs_shift >= 0 ? (t >> p.bs_shift) : (t / p.block_size); };
+  const int qc = bid % a_qchunks;
+  bid /= a_qchunks;
+  const int hg = bid % a_hgroups;
+  bid /= a_hgroups;
+  const int sp = bid % a_nsplit;
+  const int b = bid / a_nsplit;
+  const int t0 = sp * a_tps;
+  auto block_of = [&](int t) { return a_bs_shift >= 0 ? (t >> a_bs_shift) : (t / p.block_size); };
   const int lb0 = block_of(t0);
 
   // Decode mode: the first blockDim entries of this split's block-table slice are requested
@@ -85,30 +104,30 @@ __global__ void __launch_bounds__(kMaxThreads) paged_decode_kernel(const DecodeP
   if constexpr (!ROWS) {
     // (no branch around the load, so that nothing waits for it here: packed causal launches, which
     // have no table, read the first entry of their sequence offsets instead and ignore it)
-    const int end_max = min(p.max_ctx, t0 + p.tps);
+    const int end_max = min(a_max_ctx, t0 + a_tps);
     const int nlb_max = end_max > t0 ? block_of(end_max - 1) - lb0 + 1 : 1;
-    const int32_t* src = p.cu ? p.cu : p.bt + ((int64_t)b * p.max_blocks + lb0 + min(tid, nlb_max - 1));
+    const int32_t* src = a_ctx ? a_bt + ((int64_t)b * a_max_blocks + lb0 + min(tid, nlb_max - 1)) : p.cu;
     bt_first = *src;
   }
 #endif
 
-  const int hslot = wave % p.hpw, sb = wave / p.hpw;
-  const int kvh = hg * p.hpw + hslot;
+  const int hslot = wave % a_hpw, sb = wave / a_hpw;
+  const int kvh = hg * a_hpw + hslot;
   const int tl = lane / LPT, dg = lane % LPT;
 
   // Query fragments: this lane's EPL dims of each of the G query heads.  Their loads are issued
   // before the context length and the block table have arrived, so these trips to memory overlap
   // (row groups first need their rows' offsets, read below).
   int row0 = b, nrows = 1;             // ROWS: first q / out row of the group, rows in it
-  const int hq0 = ROWS ? kvh * p.gq + qc : kvh * p.gq + qc * G;
+  const int hq0 = ROWS ? kvh * a_gq + qc : kvh * a_gq + qc * G;
   u32x4 qraw[G];
   auto load_q = [&]() {
 #pragma unroll
     for (int gi = 0; gi < G; ++gi) {
-      const int hq = ROWS ? hq0 : (qc * G + gi < p.gq) ? hq0 + gi : hq0;
+      const int hq = ROWS ? hq0 : (qc * G + gi < a_gq) ? hq0 + gi : hq0;
       const int qrow = ROWS ? row0 + min(gi, nrows - 1) : b;
-      const char* src = static_cast<const char*>(p.q) +
-                        ((int64_t)qrow * p.q_stride_seq + (int64_t)hq * D + dg * EPL) * Tag::kBytes;
+      const char* src = static_cast<const char*>(a_q) +
+                        ((int64_t)qrow * a_q_stride_seq + (int64_t)hq * D + dg * EPL) * Tag::kBytes;
       qraw[gi] = load16<false>(src);
     }
   };
@@ -141,7 +160,7 @@ __global__ void __launch_bounds__(kMaxThreads) paged_decode_kernel(const DecodeP
     nrows = min(G, len - first);
     ctx0 = pos0 + first + 1;
     ctx = p.cu ? first + nrows : min(pos0 + first + nrows, p.max_ctx);
-  } else if (p.cu) {
+  } else if (!a_ctx) {   // packed causal launch (p.cu is set)
     int lo = 0, hi = p.nseq - 1;
     while (lo < hi) {  // largest s with cu[s] <= b
       const int mid = (lo + hi + 1) >> 1;
@@ -150,7 +169,7 @@ __global__ void __launch_bounds__(kMaxThreads) paged_decode_kernel(const DecodeP
     lin_start = p.cu[lo];
     ctx = b - lin_start + 1;
   } else {
-    ctx = max(0, min(p.ctx[b], p.max_ctx));
+    ctx = max(0, min(a_ctx[b], a_max_ctx));
   }
   // Splits past the context do nothing and the merge skips them; with the merge in this launch
   // split 0 always takes part, so that an empty sequence still gets its (zero) output row.
@@ -575,11 +594,16 @@ int launch_merge(const DecodeParams& p, hipStream_t stream) {
   return check_launch("paged_decode_merge_kernel");
 }
 
+#define MI355_DECODE_LEAD_ARGS(p)                                                                         \
+  (p).bt, (p).cu ? nullptr : (p).ctx, (p).q, (int)(p).q_stride_seq, (p).qchunks, (p).hgroups, (p).nsplit, (p).tps, \
+      (p).bs_shift, (p).max_blocks, (p).max_ctx, (p).hpw, (p).gq
+
 template <class Tag, int D, int G>
 int launch_decode(const DecodeParams& p, const DecodePlan& pl, hipStream_t stream) {
   const int64_t grid = (int64_t)p.B * p.nsplit * p.hgroups * p.qchunks;
+  if (p.q_stride_seq >= (1LL << 31)) return fail(MI355_EINVAL, "paged_decode: q row stride out of range");
   hipLaunchKernelGGL((paged_decode_kernel<Tag, D, G, steps_for_group(G), MI355_DECODE_NT != 0>), dim3((unsigned)grid),
-                     dim3(pl.nw * kWave), pl.lds_bytes, stream, p);
+                     dim3(pl.nw * kWave), pl.lds_bytes, stream, MI355_DECODE_LEAD_ARGS(p), p);
   if (int rc = check_launch("paged_decode_kernel")) return rc;
   if (p.nsplit > 1 && !p.counters) return launch_merge<Tag, D>(p, stream);
   return 0;
@@ -597,7 +621,8 @@ int launch_causal_rows(const DecodeParams& p, size_t lds_bytes, hipStream_t stre
                             (int)lds_bytes) != hipSuccess)
       return fail(MI355_EUNSUPPORTED, "row-group kernel: %zu bytes of LDS refused", lds_bytes);
   }
-  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(8 * kWave), lds_bytes, stream, p);
+  if (p.q_stride_seq >= (1LL << 31)) return fail(MI355_EINVAL, "prefill: q row stride out of range");
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(8 * kWave), lds_bytes, stream, MI355_DECODE_LEAD_ARGS(p), p);
   return check_launch("paged_decode_kernel (causal row groups)");
 }
 
