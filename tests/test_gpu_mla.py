@@ -90,6 +90,34 @@ def test_mla_decode_fp32_kernel(ops, device, shape):
     np.testing.assert_allclose(out.cpu().numpy(), want, atol=2e-5, rtol=1e-4)
 
 
+@pytest.mark.parametrize('shape', [(2, 16, 512, 64, 300), (2, 8, 256, 32, 130), (3, 4, 128, 16, 77), (2, 5, 32, 8, 50)])
+def test_mla_decode_fp32_unaligned_rope_rows(ops, device, shape):
+    """k_rope rows that do not start on 16-byte boundaries (a view one element into a wider buffer)
+    take the fp32 kernel's element-by-element loads; same arithmetic as the 16-byte form, so the
+    results are equal bit for bit, and both meet the oracle."""
+    seqs, H, R, P, max_ctx = shape
+    rng = np.random.default_rng(sum(shape) + 7)
+    S = max_ctx
+    q = rng.standard_normal((seqs, H, R + P), dtype=np.float32) * 0.5
+    c_kv = rng.standard_normal((seqs, S, R), dtype=np.float32)
+    k_rope = rng.standard_normal((seqs, S, P), dtype=np.float32)
+    ctx = rng.integers(1, max_ctx + 1, size=seqs).astype(np.int32)
+    ctx[0] = max_ctx
+    cos, sin = mo.rope_tables(P, S + 3)
+    scale = 0.09
+    want = mo.latent_attention(q, c_kv, k_rope, cos, sin, ctx, scale)
+    t = lambda a: torch.from_numpy(a).to(device)
+    aligned = ops.mla_decode(t(q), t(c_kv), t(k_rope), t(cos), t(sin), t(ctx), max_ctx, scale)
+    wide = torch.zeros((seqs, S, P + 3), dtype=torch.float32, device=device)
+    view = wide[:, :, 1:1 + P]
+    view.copy_(t(k_rope))
+    assert view.data_ptr() % 16 != 0 and view.stride(2) == 1
+    shifted = ops.mla_decode(t(q), t(c_kv), view, t(cos), t(sin), t(ctx), max_ctx, scale)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(aligned.cpu().numpy(), want, atol=2e-5, rtol=1e-4)
+    assert torch.equal(aligned, shifted)
+
+
 def test_mla_decode_config4_shape(ops, device):
     """BASELINE config 4: kv_lora_rank=512, rope 64, context 4096 (split path), checked on a few rows."""
     rng = np.random.default_rng(4)
