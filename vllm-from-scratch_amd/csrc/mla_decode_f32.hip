@@ -33,6 +33,10 @@ namespace {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+#ifndef MI355_MLA_F32_TILES
+#define MI355_MLA_F32_TILES 3
+#endif
+
 struct MlaF32Params {
   float* out;
   const float* q;
@@ -171,6 +175,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) mla_decode_f32_kernel(const Mla
   };
 
   const int ntiles = ctx > tok0 ? (ctx - tok0 + 15) / 16 : 0;
+  constexpr int kTiles = MI355_MLA_F32_TILES;   // register tiles in rotation
   float* my_v = s_v[wave];
   f32x4v sc_ahead = {0.f, 0.f, 0.f, 0.f};    // one wave: the scores computed one tile ahead stay in registers
 
@@ -274,20 +279,21 @@ __global__ void __launch_bounds__(WAVES * 64, 2) mla_decode_f32_kernel(const Mla
       __builtin_amdgcn_sched_group_barrier(0x008, kVAhead, 0);
     }
     stash(ready);                      // tile t + 1 (after this wave's reads of tile t: LDS runs a wave's accesses in order)
-    load_tile(t0 + 48, ready);         // tile t + 3
+    load_tile(t0 + 16 * (kTiles + 1), ready);   // tile t + kTiles + 1
     if constexpr (WAVES > 1) __syncthreads();
   };
   if (ntiles > 0) {
-    Tile ta, tb;
-    load_tile(tok0, tb);
-    load_tile(tok0 + 16, ta);
-    scores(0, tb);
-    stash(tb);
-    load_tile(tok0 + 32, tb);
+    Tile tl[kTiles];
+    load_tile(tok0, tl[kTiles - 1]);
+#pragma unroll
+    for (int i = 0; i < kTiles - 1; ++i) load_tile(tok0 + 16 * (i + 1), tl[i]);
+    scores(0, tl[kTiles - 1]);
+    stash(tl[kTiles - 1]);
+    load_tile(tok0 + 16 * kTiles, tl[kTiles - 1]);
     if constexpr (WAVES > 1) __syncthreads();
-    for (int t = 0; t < ntiles; t += 2) {
-      step(t, ta);
-      step(t + 1, tb);
+    for (int t = 0; t < ntiles; t += kTiles) {
+#pragma unroll
+      for (int i = 0; i < kTiles; ++i) step(t + i, tl[i]);
     }
   }
 
