@@ -112,7 +112,7 @@ __device__ __forceinline__ void load_run(const float* src, float (&dst)[RS]) {
 }
 
 template <int R, int P, int WAVES, bool VEC>
-__global__ void __launch_bounds__(WAVES * 64, 2) mla_decode_f32_kernel(const MlaF32Params p) {
+__global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) mla_decode_f32_kernel(const MlaF32Params p) {
   constexpr int Q = R / WAVES;            // latent dims per wave
   constexpr int NJ = Q / 16;              // 16-dim groups per wave
   constexpr int PR = P / (2 * WAVES);     // rope dims per wave in each half
@@ -175,7 +175,9 @@ __global__ void __launch_bounds__(WAVES * 64, 2) mla_decode_f32_kernel(const Mla
   };
 
   const int ntiles = ctx > tok0 ? (ctx - tok0 + 15) / 16 : 0;
-  constexpr int kTiles = MI355_MLA_F32_TILES;   // register tiles in rotation
+  // register tiles in rotation: three for the four-wave kernels (44 registers per tile at rank 512 / rope 64:
+  // 256 VGPRs, no scratch); the one-wave kernels hold whole rows (up to 80 registers per tile) and keep two
+  constexpr int kTiles = WAVES == 4 ? MI355_MLA_F32_TILES : 2;
   float* my_v = s_v[wave];
   f32x4v sc_ahead = {0.f, 0.f, 0.f, 0.f};    // one wave: the scores computed one tile ahead stay in registers
 
