@@ -283,6 +283,18 @@ def test_engine_matches_reference_in_compat_mode(mv, dev):
         np.testing.assert_allclose(got.float().cpu().numpy(), want, atol=2e-4, rtol=1e-4)
 
 
+def test_benchmark_throughput_runs_the_reference_configuration(mv, device, capsys):
+    """benchmark_throughput() (05_mini_vllm/mini_vllm.py:936-974): 16 requests x 20 new tokens on the
+    reference's configuration; returns output tokens per second and prints the reference's fields."""
+    import re
+    rate = mv.benchmark_throughput()
+    out = capsys.readouterr().out
+    assert rate > 0
+    assert "concurrent requests: 16" in out and "tok/s" in out
+    n_out = int(re.search(r"output tokens: (\d+)", out).group(1))
+    assert 16 <= n_out <= 320          # 20 new tokens per request unless an end-of-sequence id is drawn first
+
+
 def test_engine_true_context_decode(mv, device):
     """Default mode: the prompt step equals the reference's (it has no history to miss); decode
     steps attend to the whole paged context, which must equal a dense recomputation of the same

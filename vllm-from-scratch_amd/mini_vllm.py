@@ -1736,3 +1736,35 @@ class DataParallelMiniVLLM:
             step += 1
         gather.drain()        # the last launch carried no tokens: nobody had work when it was issued
         return outputs
+
+
+def benchmark_throughput(dtype=None, warm_passes: int = 1):
+    """Output tokens per second of generate() on the configuration the reference benchmarks
+    (05_mini_vllm/mini_vllm.py:936-974: vocabulary 1000, hidden 256, 4 layers, 8 heads, intermediate
+    1024, 256 KV blocks of 16, 16 sequence slots, 1024-token budget; 16 prompts of 10-50 random
+    tokens, 20 new tokens each, temperature-1 sampling), measured as the reference measures it:
+    wall clock around one generate() call.  `warm_passes` untimed calls come first (the first call
+    on a fresh engine also captures its steps; 0 times the cold call, as the reference does).
+    Needs a HIP device.  Prints the figures and returns output tokens per second.
+    """
+    import random
+    import time
+    engine = MiniVLLM(vocab_size=1000, hidden_size=256, num_layers=4, num_heads=8, intermediate_size=1024,
+                      num_kv_blocks=256, block_size=16, max_num_seqs=16, max_num_batched_tokens=1024,
+                      device='cuda', dtype=dtype)
+    prompts = [[random.randint(1, 999) for _ in range(random.randint(10, 50))] for _ in range(16)]
+    for _ in range(warm_passes):
+        engine.generate(prompts, max_new_tokens=20)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outputs = engine.generate(prompts, max_new_tokens=20)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    n_out = sum(len(v) for v in outputs.values())
+    print("benchmark_throughput:")
+    print(f"  concurrent requests: {len(prompts)}")
+    print(f"  input tokens: {sum(len(p) for p in prompts)}")
+    print(f"  output tokens: {n_out}")
+    print(f"  elapsed: {elapsed:.3f}s")
+    print(f"  output throughput: {n_out / elapsed:.1f} tok/s")
+    return n_out / elapsed
