@@ -137,7 +137,12 @@ __global__ void __launch_bounds__(kWaves * kWave, 2) MI355_NO_PACKED_F32 prefill
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 31, h = lane >> 5;
   int bid = blockIdx.x;
-  const int hq = bid % p.Hq;
+  // Workgroups b and b + 8 share an XCD (and its L2).  With the head index taken as b % Hq, the
+  // query heads of one kv group (consecutive heads) would sit on different XCDs and each K/V tile
+  // would be fetched into several L2s; slot b % 8 takes Hq / 8 consecutive heads instead, so a kv
+  // group's heads -- and all query tiles of a head -- share one L2.
+  const int hslot = bid % p.Hq;
+  const int hq = (p.Hq & 7) == 0 ? (hslot & 7) * (p.Hq >> 3) + (hslot >> 3) : hslot;
   bid /= p.Hq;
   const int qt = p.n_qt_max - 1 - (bid % p.n_qt_max);   // long (late) tiles are issued first
   const int seq = bid / p.n_qt_max;
