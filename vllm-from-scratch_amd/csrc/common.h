@@ -274,6 +274,29 @@ __device__ __forceinline__ int warm_kernel_arguments() {
   return zero;
 }
 
+// Block index -> (head tile, token split, row).  The head tiles of one (row, split) read the same
+// cached rows.  Workgroups b and b + 8 share an XCD and its L2, so within every run of 8 * n_ht
+// consecutive blocks the head tile is taken from b / 8 and the (row, split) from b % 8: the tiles of
+// a (row, split) sit on one XCD and the second reader finds the rows in that L2 (taken as b % n_ht,
+// they would sit on neighbouring XCDs and each fetch the rows from memory).  The blocks past the
+// last full run keep the plain order.
+__device__ __forceinline__ void split_block_index(int b, int n_ht, int nsplit, int rows, int& ht, int& sp, int& row) {
+  const int items = rows * nsplit;                 // (row, split) pairs
+  const int run = 8 * n_ht, full = items / 8;      // `full` runs of 8 pairs x n_ht tiles
+  int item;
+  if (n_ht > 1 && b < full * run) {
+    const int r = b / run, i = b - r * run;
+    item = r * 8 + (i & 7);
+    ht = i >> 3;
+  } else {
+    const int t = n_ht > 1 ? b - full * run : b;
+    item = (n_ht > 1 ? full * 8 : 0) + t / n_ht;
+    ht = t % n_ht;
+  }
+  sp = item % nsplit;
+  row = item / nsplit;
+}
+
 template <bool NT>
 __device__ __forceinline__ u32x4 load16(const void* p) {
   if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));

@@ -95,11 +95,8 @@ __global__ void __launch_bounds__(kWave) mla_decode_kernel(const MlaParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char tile[kTok * ROWB];
 
   const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
-  int bid = blockIdx.x;
-  const int ht = bid % p.n_ht;
-  bid /= p.n_ht;
-  const int sp = bid % p.nsplit;
-  const int row = bid / p.nsplit;
+  int ht, sp, row;
+  split_block_index(blockIdx.x, p.n_ht, p.nsplit, p.rows, ht, sp, row);
   const int seq = p.row_seq ? p.row_seq[row] : row;
   const int ctx = max(0, min(p.ctx[row], p.max_ctx));
   const int t_begin = sp * p.tps;
@@ -256,11 +253,8 @@ __global__ void __launch_bounds__(256, 2) mla_decode_kernel_w4(const MlaParams p
   __shared__ f32x4 part[4][kWave];        // per-wave partial scores of the current tile
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
-  int bid = blockIdx.x;
-  const int ht = bid % p.n_ht;
-  bid /= p.n_ht;
-  const int sp = bid % p.nsplit;
-  const int row = bid / p.nsplit;
+  int ht, sp, row;
+  split_block_index(blockIdx.x, p.n_ht, p.nsplit, p.rows, ht, sp, row);
   const int seq = p.row_seq ? p.row_seq[row] : row;
   const int ctx = max(0, min(p.ctx[row], p.max_ctx));
   const int t_begin = sp * p.tps;
@@ -502,11 +496,8 @@ __global__ void __launch_bounds__(256) mla_decode_kernel_mh(const MlaParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char tiles[2][kTok2 * ROWB];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
-  int bid = blockIdx.x;
-  const int ht = bid % p.n_ht;
-  bid /= p.n_ht;
-  const int sp = bid % p.nsplit;
-  const int row = bid / p.nsplit;
+  int ht, sp, row;
+  split_block_index(blockIdx.x, p.n_ht, p.nsplit, p.rows, ht, sp, row);
   const int seq = p.row_seq ? p.row_seq[row] : row;
   const int ctx = max(0, min(p.ctx[row], p.max_ctx));
   const int t_begin = sp * p.tps;

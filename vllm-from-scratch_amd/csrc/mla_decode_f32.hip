@@ -124,10 +124,8 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) mla_decode_f32
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
-  int bid = blockIdx.x;
-  const int ht = bid % p.n_ht;
-  bid /= p.n_ht;
-  const int sp = bid % p.nsplit, row = bid / p.nsplit;
+  int ht, sp, row;
+  split_block_index(blockIdx.x, p.n_ht, p.nsplit, p.rows, ht, sp, row);
   const int seq = p.row_seq ? p.row_seq[row] : row;
   const int ctx_all = max(0, min(p.ctx[row], p.max_ctx));
   const int tok0 = sp * p.tps;                             // this split's tokens: [tok0, ctx)
