@@ -54,10 +54,12 @@ CONFIGS = {
 }
 
 
-def algorithmic_bytes(B, S, Hq, Hkv, D, BS, esize):
-    """Bytes one decode launch must move: K and V rows, q and out, block table, context lens."""
+def algorithmic_bytes(B, S, Hq, Hkv, D, BS, esize, append=False):
+    """Bytes one decode launch must move: K and V rows, q and out, block table, context lens;
+    with the cache write in the launch, also the new K/V rows read and stored."""
     nblk = (S + BS - 1) // BS
-    return B * S * Hkv * D * 2 * esize + 2 * B * Hq * D * esize + 4 * B * nblk + 4 * B
+    new_rows = 2 * (2 * B * Hkv * D * esize) if append else 0
+    return B * S * Hkv * D * 2 * esize + 2 * B * Hq * D * esize + 4 * B * nblk + 4 * B + new_rows
 
 
 def build_inputs(cfg, device, seed, sets=2):
@@ -178,6 +180,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--config', default='metric', choices=sorted(CONFIGS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--fused-step', action='store_true',
+                    help='cache write and attention in one call (mi355_paged_decode_append) instead of the two calls '
+                         'of the reference step (mi355_kv_write_slots, mi355_paged_decode); named in config.workload')
     ap.add_argument('--strong', type=int, default=0, metavar='TOTAL',
                     help='strong scaling: TOTAL sequences over all ranks (TOTAL / N per GPU, e.g. 2048) instead of '
                          'the fixed per-GPU batch; reported as "scaling": "strong"')
@@ -241,12 +246,22 @@ def main():
     ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(ROOFLINE_LAUNCHES)]
     ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(ROOFLINE_LAUNCHES)]
 
+    # Cache write + attention of the step: one call (the wave that reads a sequence's last position
+    # stores the new row there first), or the two calls it replaces.
+    def attend(kc, vc, bt):
+        if not args.fused_step:
+            ops.paged_decode(inp['q'], kc, vc, bt, inp['ctx'], S, layout='NHSD', out=out)
+        else:
+            ops.paged_decode_append(inp['q'], inp['k_new'], inp['v_new'], kc, vc, bt, inp['ctx'], S, layout='NHSD',
+                                    out=out)
+
     def step(i, bracket=None):
         kc, vc, bt = inp['pools'][i % nsets]
-        ops.kv_write_slots(kc, vc, inp['k_new'], inp['v_new'], inp['slots'][i % nsets], 'NHSD')
+        if not args.fused_step:
+            ops.kv_write_slots(kc, vc, inp['k_new'], inp['v_new'], inp['slots'][i % nsets], 'NHSD')
         if bracket is not None:
             ev_a[bracket].record()
-        ops.paged_decode(inp['q'], kc, vc, bt, inp['ctx'], S, layout='NHSD', out=out)
+        attend(kc, vc, bt)
         if bracket is not None:
             ev_b[bracket].record()
         if bracket is None:
@@ -303,14 +318,14 @@ def main():
             g_a[g].record()
             for j in range(ROOFLINE_GROUP):
                 kc, vc, bt = inp['pools'][(g * ROOFLINE_GROUP + j) % nsets]
-                ops.paged_decode(inp['q'], kc, vc, bt, inp['ctx'], S, layout='NHSD', out=out)
+                attend(kc, vc, bt)
             g_b[g].record()
         torch.cuda.synchronize()
         kernel_ms = sorted(g_a[g].elapsed_time(g_b[g]) / ROOFLINE_GROUP for g in range(ROOFLINE_GROUPS))
         avg_ms = sum(kernel_ms) / len(kernel_ms)
     if use_dist:
         dist.barrier()
-    abytes = algorithmic_bytes(B, S, H, H, D, BS, 2)
+    abytes = algorithmic_bytes(B, S, H, H, D, BS, 2, append=args.fused_step)
 
     if rank == 0:
         achieved = abytes / (avg_ms * 1e-3) / 1e9
@@ -327,14 +342,17 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"paged decode step: batch={B}/GPU, ctx={S}, heads={H}, head_dim={D}, "
                                    f"block_size={BS}, bf16 KV [blocks,heads,{BS},{D}], scattered block table; "
-                                   f"kv-write + paged attention + greedy argmax(vocab={cfg['vocab']})"
+                                   + ("kv-write and paged attention in one launch" if args.fused_step else
+                                      "kv-write + paged attention")
+                                   + f" + greedy argmax(vocab={cfg['vocab']})"
                                    + (" + RCCL all-gather of ids, one collective per step" if use_dist and args.gather_every == 1
                                       else f" + RCCL all-gather of ids, BATCHED: one collective per {args.gather_every} steps"
                                       if use_dist else ""),
                        "batch_per_gpu": B, "context": S, "block_size": BS, "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "mi355_paged_decode (paged_decode_kernel + split merge)",
+                         "kernel": "mi355_paged_decode_append (paged_decode_kernel, append mode)" if args.fused_step
+                                   else "mi355_paged_decode (paged_decode_kernel + split merge)",
                          "algorithmic_bytes_per_launch": abytes,
                          "avg_launch_ms": round(avg_ms, 5),
                          "launches_timed": ROOFLINE_GROUPS * ROOFLINE_GROUP,

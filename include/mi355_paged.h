@@ -131,6 +131,41 @@ int mi355_paged_decode_static(void* out, const void* q, int64_t q_stride_seq,
                               float scale, int32_t dtype, void* stream);
 
 /*
+ * One decode step of an attention layer in one call: store every sequence's newest K/V row in
+ * its cache, then attend.  Replaces the decode branch of SelfAttention.forward as a whole --
+ * the indexed cache assignment 05_mini_vllm/mini_vllm.py:421-427 followed by the per-sequence
+ * attention :460-481 (01_paged_attention/paged_attention.py:48-51 + :67-101) -- and equals
+ * mi355_kv_write_slots followed by mi355_paged_decode bit for bit, caches included:
+ *
+ *   for b in [0,B) with 1 <= context_lens[b] <= min(max_context, max_blocks*block_size):
+ *     position context_lens[b] - 1 of sequence b (block block_tables[b][(ctx-1) / block_size],
+ *     row (ctx-1) % block_size, every kv head) := k_new[b], v_new[b]
+ *   then out = mi355_paged_decode(q, caches, block_tables, context_lens)
+ *
+ * i.e. context_lens already counts the new token, as it does after write_kv in the reference.
+ * Rows with context_lens[b] < 1 or beyond the bound write nothing.
+ *   k_new, v_new  [B, Hkv, D], new_stride_seq elements between sequences, 16-B aligned
+ *   k_cache,
+ *   v_cache       written at B * Hkv rows, otherwise read; all other arguments as in
+ *                 mi355_paged_decode (same workspace query)
+ * On shapes the VALU decode kernel serves, the wave that reads a sequence's last position
+ * stores the row there first: no launch of its own for the write.  Grouped-query shapes on the
+ * matrix-core kernel get the write as a small launch ahead of the attention launch.
+ * A slot written for one sequence must not lie within another sequence's context in the same
+ * call: that reader may see the slot before or after the write.
+ */
+int mi355_paged_decode_append(void* out, const void* q, int64_t q_stride_seq,
+                              const void* k_new, const void* v_new, int64_t new_stride_seq,
+                              void* k_cache, void* v_cache,
+                              const int32_t* block_tables, const int32_t* context_lens,
+                              int32_t B, int32_t Hq, int32_t Hkv, int32_t D,
+                              int32_t block_size, int32_t max_blocks, int32_t num_blocks,
+                              int32_t max_context,
+                              int64_t kv_stride_block, int64_t kv_stride_head, int64_t kv_stride_tok,
+                              float scale, int32_t dtype,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * Scatter T new K/V rows into the paged caches by flat slot id
  * (slot = block*block_size + row).  Replaces the per-token write loops
  * 01_paged_attention/paged_attention.py:118-123, KVCachePool.write_kv (:48-51)

@@ -1,0 +1,132 @@
+"""mi355_paged_decode_append: cache write and attention of a decode step in one call (needs an MI355X).
+
+The bar is bit-equality, output and caches, with the two calls it replaces -- mi355_kv_write_slots
+at every sequence's last position followed by mi355_paged_decode -- which the other kernel tests
+hold against the oracle and the golden vectors.  Before the fused call the slots to be written hold
+NaN, so a read that did not wait for the write would show in the output.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from mi355_paged import ops as _ops
+    return _ops
+
+
+def _problem(rng, device, dtype, B, Hq, Hkv, D, BS, max_ctx, layout, ctx=None, spare=5):
+    ctx = np.asarray(ctx if ctx is not None else rng.integers(1, max_ctx + 1, size=B), dtype=np.int64)
+    per = (max_ctx + BS - 1) // BS
+    NB = B * per + spare
+    bt = rng.permutation(NB)[:B * per].reshape(B, per).astype(np.int32)
+    cache = torch.from_numpy(rng.standard_normal((2, NB, Hkv, BS, D), dtype=np.float32)).to(device=device, dtype=dtype)
+    if layout == 'NSHD':
+        cache = cache.permute(0, 1, 3, 2, 4).contiguous()
+    q = torch.from_numpy(rng.standard_normal((B, Hq, D), dtype=np.float32)).to(device=device, dtype=dtype)
+    kn = torch.from_numpy(rng.standard_normal((B, Hkv, D), dtype=np.float32)).to(device=device, dtype=dtype)
+    vn = torch.from_numpy(rng.standard_normal((B, Hkv, D), dtype=np.float32)).to(device=device, dtype=dtype)
+    last = np.maximum(ctx - 1, 0)
+    slots = bt[np.arange(B), last // BS].astype(np.int64) * BS + last % BS
+    slots[ctx < 1] = -1
+    return dict(q=q, kn=kn, vn=vn, cache=cache, bt=torch.from_numpy(bt).to(device),
+                ctx=torch.from_numpy(ctx.astype(np.int32)).to(device), slots=torch.from_numpy(slots).to(device),
+                max_ctx=int(max_ctx), layout=layout, BS=BS)
+
+
+def _poison(pr, cache):
+    """NaN in the rows the step is going to write."""
+    s = pr['slots'][pr['slots'] >= 0]
+    blk, row = s // pr['BS'], s % pr['BS']
+    for c in (cache[0], cache[1]):
+        if pr['layout'] == 'NHSD':
+            c[blk, :, row, :] = float('nan')
+        else:
+            c[blk, row, :, :] = float('nan')
+
+
+def _both_ways(ops, pr):
+    two = pr['cache'].clone()
+    _poison(pr, two)
+    one = two.clone()
+    ops.kv_write_slots(two[0], two[1], pr['kn'], pr['vn'], pr['slots'], layout=pr['layout'])
+    want = ops.paged_decode(pr['q'], two[0], two[1], pr['bt'], pr['ctx'], pr['max_ctx'], layout=pr['layout'])
+    got = ops.paged_decode_append(pr['q'], pr['kn'], pr['vn'], one[0], one[1], pr['bt'], pr['ctx'], pr['max_ctx'],
+                                  layout=pr['layout'])
+    torch.cuda.synchronize()
+    return want, got, two, one
+
+
+def _assert_same(want, got, two, one):
+    assert not torch.isnan(got.float()).any()
+    assert torch.equal(want.view(torch.uint8), got.view(torch.uint8))
+    assert torch.equal(two.view(torch.uint8), one.view(torch.uint8))   # (bytes: the untouched NaN rows compare equal)
+
+
+@pytest.mark.parametrize('layout', ['NHSD', 'NSHD'])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32, torch.float16])
+@pytest.mark.parametrize('shape', [
+    # B, Hq, Hkv, D, BS, max_ctx
+    (9, 8, 8, 64, 16, 700),       # one kv head per workgroup, eight sub-ranges
+    (5, 8, 4, 64, 16, 300),       # two query heads per kv head on the VALU kernel
+    (4, 8, 2, 32, 8, 130), (3, 8, 1, 128, 16, 257), (3, 4, 4, 16, 4, 50), (2, 6, 6, 256, 16, 40),
+    (7, 8, 8, 64, 3, 100),        # block size that is not a power of two
+    (3, 12, 4, 64, 16, 90),       # three query heads per kv head: two chunks of workgroups write the same rows
+    (2, 8, 8, 64, 16, 9000),      # token splits merged in the launch
+    (1, 8, 8, 64, 16, 40000),     # more splits than the launch merges itself: merge kernel behind it
+    (3, 32, 8, 128, 16, 300),     # grouped-query shape on the matrix cores (16-bit): the write is its own launch
+    (40, 8, 8, 64, 16, 33),       # short contexts: the written row is read by the first loads
+])
+def test_append_equals_write_then_decode(ops, device, shape, dtype, layout):
+    B, Hq, Hkv, D, BS, max_ctx = shape
+    rng = np.random.default_rng(abs(hash((shape, str(dtype), layout))) % (2 ** 31))
+    pr = _problem(rng, device, dtype, B, Hq, Hkv, D, BS, max_ctx, layout)
+    _assert_same(*_both_ways(ops, pr))
+
+
+def test_append_every_short_context_and_block_edge(ops, device):
+    """Contexts 0 .. 200 in one batch (empty rows write nothing and give zeros): the written row in
+    the first, second and later pipeline steps of its wave, on and off block boundaries."""
+    rng = np.random.default_rng(7)
+    ctx = np.arange(0, 201)
+    for dtype, D, Hkv in ((torch.bfloat16, 64, 8), (torch.float32, 64, 8), (torch.bfloat16, 128, 2)):
+        pr = _problem(rng, device, dtype, len(ctx), 8, Hkv, D, 16, 200, 'NHSD', ctx=ctx)
+        want, got, two, one = _both_ways(ops, pr)
+        _assert_same(want, got, two, one)
+        assert float(got[0].float().abs().max()) == 0.0
+
+
+def test_append_at_the_metric_shape_subset(ops, device):
+    """The benchmark's plan (8 heads, head_dim 64, block 16, context 2048, bf16), 64 sequences."""
+    rng = np.random.default_rng(11)
+    pr = _problem(rng, device, torch.bfloat16, 64, 8, 8, 64, 16, 2048, 'NHSD', ctx=np.full(64, 2048))
+    _assert_same(*_both_ways(ops, pr))
+    pr = _problem(rng, device, torch.bfloat16, 64, 8, 8, 64, 16, 1024, 'NHSD', ctx=np.full(64, 1024))
+    _assert_same(*_both_ways(ops, pr))
+
+
+def test_append_context_beyond_the_bound_writes_nothing(ops, device):
+    rng = np.random.default_rng(3)
+    pr = _problem(rng, device, torch.bfloat16, 4, 8, 8, 64, 16, 128, 'NHSD', ctx=[128, 60, 128, 17])
+    pr['ctx'][1] = 500                     # beyond max_context: attends to the bound, writes nothing
+    before = pr['cache'].clone()
+    slots = pr['slots'].clone()
+    slots[1] = -1
+    pr['slots'] = slots
+    want, got, two, one = _both_ways(ops, pr)
+    assert torch.equal(want.view(torch.uint8), got.view(torch.uint8))
+    assert torch.equal(two.view(torch.uint8), one.view(torch.uint8))
+    del before
+
+
+def test_append_bad_arguments(ops, device):
+    rng = np.random.default_rng(5)
+    pr = _problem(rng, device, torch.bfloat16, 2, 8, 8, 64, 16, 64, 'NHSD')
+    c = pr['cache']
+    with pytest.raises(ValueError):
+        ops.paged_decode_append(pr['q'], pr['kn'][:, :4], pr['vn'][:, :4], c[0], c[1], pr['bt'], pr['ctx'], 64)
+    with pytest.raises(TypeError):
+        ops.paged_decode_append(pr['q'], pr['kn'].float(), pr['vn'].float(), c[0], c[1], pr['bt'], pr['ctx'], 64)

@@ -74,5 +74,10 @@ step secondary benchmarks
   BENCH_FORCE_DIST=1 timeout -k 10 200 python3 bench.py --no-cpu-baseline --gather-every 4 | cut -c1-200
   BENCH_FORCE_DIST=1 BENCH_NATIVE_RCCL=1 timeout -k 10 200 python3 bench.py --no-cpu-baseline | cut -c1-200
   timeout -k 10 200 python3 bench.py --no-cpu-baseline | cut -c1-200
+  echo "cache write + attention in one launch (--fused-step) against the two launches of the default step: metric config, config 2"
+  timeout -k 10 200 python3 bench.py --no-cpu-baseline --fused-step
+  timeout -k 10 200 python3 bench.py --no-cpu-baseline
+  timeout -k 10 200 python3 bench.py --no-cpu-baseline --config c2 --fused-step
+  timeout -k 10 200 python3 bench.py --no-cpu-baseline --config c2
 } > "$OUT/secondary.txt" 2> "$OUT/secondary.err"
 find "$OUT" -name '*.csv' | head -40 >&2

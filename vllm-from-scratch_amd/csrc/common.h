@@ -262,15 +262,16 @@ __device__ __forceinline__ int warm_kernel_arguments() {
   typedef const __attribute__((address_space(4))) uint32_t* karg_t;
   karg_t ka = (karg_t)__builtin_amdgcn_kernarg_segment_ptr() + OFFSET / 4;
   constexpr int kLines = (BYTES + 63) / 64;
-  static_assert(kLines <= 4, "argument block longer than 256 bytes");
-  uint32_t w[4];
+  static_assert(kLines <= 5, "argument block longer than 320 bytes");
+  uint32_t w[5];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 5; ++i) {
     const int line = i < kLines ? i : kLines - 1;
     w[i] = ka[(line * 64 < BYTES - 4 ? line * 64 : BYTES - 4) / 4];
   }
   int zero;
-  asm("s_mov_b32 %0, 0" : "=s"(zero) : "s"(w[0]), "s"(w[1]), "s"(w[2]), "s"(w[3]));
+  if constexpr (kLines <= 4) asm("s_mov_b32 %0, 0" : "=s"(zero) : "s"(w[0]), "s"(w[1]), "s"(w[2]), "s"(w[3]));
+  else asm("s_mov_b32 %0, 0" : "=s"(zero) : "s"(w[0]), "s"(w[1]), "s"(w[2]), "s"(w[3]), "s"(w[4]));
   return zero;
 }
 

@@ -40,6 +40,14 @@ struct DecodeParams {
   // arrival cell per (sequence, kv-head group, q-head chunk), holding (launch tag << 16) | arrivals.
   unsigned long long* counters = nullptr;
   unsigned long long epoch = 0;
+  // Append mode of the VALU kernel: the K/V row of every sequence's newest token ([B, Hkv, D],
+  // new_stride_seq elements between sequences) belongs at position context - 1 of its cache; the
+  // wave whose token range holds that position attends to the row from LDS (lds_new_off: where
+  // the waves' copies start in dynamic LDS) and stores it to the cache at its end.
+  const void* k_new = nullptr;
+  const void* v_new = nullptr;
+  int64_t new_stride_seq = 0;
+  int lds_new_off = 0;
 };
 
 struct DecodePlan {

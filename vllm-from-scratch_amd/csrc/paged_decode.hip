@@ -68,7 +68,10 @@ struct DecodeLead {
   int qchunks, hgroups, nsplit, tps, bs_shift, max_blocks, max_ctx, hpw, gq;
 };
 
-template <class Tag, int D, int G, int U, bool NT, bool ROWS = false>
+// APPEND (decode mode only): every sequence's newest K/V row arrives as an argument instead of
+// sitting in the cache already.  The wave whose token range holds the last position stores the
+// row there before it reads it, so the step's cache write needs no launch of its own.
+template <class Tag, int D, int G, int U, bool NT, bool ROWS = false, bool APPEND = false>
 __global__ void __launch_bounds__(kMaxThreads)
 paged_decode_kernel(const int32_t* a_bt, const int32_t* a_ctx, const void* a_q, int a_q_stride_seq, int a_qchunks,
                     int a_hgroups, int a_nsplit, int a_tps, int a_bs_shift, int a_max_blocks, int a_max_ctx,
@@ -81,7 +84,8 @@ paged_decode_kernel(const int32_t* a_bt, const int32_t* a_ctx, const void* a_q, 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #if MI355_DECODE_EARLY_BT && MI355_DECODE_WARM
-  int bid = blockIdx.x + warm_kernel_arguments<sizeof(DecodeParams), kLeadBytes>();
+  // (the new-row fields at the end of DecodeParams are only read in append mode)
+  int bid = blockIdx.x + warm_kernel_arguments<APPEND ? sizeof(DecodeParams) : offsetof(DecodeParams, k_new), kLeadBytes>();
 #else
   int bid = blockIdx.x;
 #endif
@@ -132,11 +136,20 @@ paged_decode_kernel(const int32_t* a_bt, const int32_t* a_ctx, const void* a_q, 
     }
   };
   if constexpr (!ROWS) load_q();
+  // Append mode: this lane's piece of the head's new K and V row (every token group of the wave
+  // loads the same 16 bytes: no branch around the loads, and any lane group can store them)
+  u32x4 new_k = {0u, 0u, 0u, 0u}, new_v = {0u, 0u, 0u, 0u};
+  if constexpr (APPEND) {
+    const int64_t src = ((int64_t)b * p.new_stride_seq + (int64_t)kvh * D + dg * EPL) * Tag::kBytes;
+    new_k = load16<false>(static_cast<const char*>(p.k_new) + src);
+    new_v = load16<false>(static_cast<const char*>(p.v_new) + src);
+  }
 
   // Causal mode (prompt processing): "sequence" b is query token b of a packed
   // batch; it attends to tokens start..b of its own prompt, which sit in k/v rows
   // start..b (block_size 1, physical id = token row).  No block table is read.
   int ctx, lin_start = 0;
+  int ctx_given = 0;                   // decode mode: the context length as the caller gave it
   int ctx0 = 0;                        // ROWS: context of the group's first row
   int bt_row = b;                      // row of the block table this workgroup reads
   if constexpr (ROWS) {
@@ -169,7 +182,8 @@ paged_decode_kernel(const int32_t* a_bt, const int32_t* a_ctx, const void* a_q, 
     lin_start = p.cu[lo];
     ctx = b - lin_start + 1;
   } else {
-    ctx = max(0, min(a_ctx[b], a_max_ctx));
+    ctx_given = a_ctx[b];
+    ctx = max(0, min(ctx_given, a_max_ctx));
   }
   // Splits past the context do nothing and the merge skips them; with the merge in this launch
   // split 0 always takes part, so that an empty sequence still gets its (zero) output row.
@@ -193,7 +207,11 @@ paged_decode_kernel(const int32_t* a_bt, const int32_t* a_ctx, const void* a_q, 
     s_bt[i] = min(max(id, 0), p.num_blocks - 1);
   }
   __syncthreads();
-
+  // Append mode: the new row's pieces have arrived by now (requested with q, ahead of the table
+  // entry the barrier waited for).  Taking them here, in every wave, keeps a load that most waves
+  // never use from standing in the way of the stream's own loads: a register whose load might
+  // still be pending cannot be reused without waiting for everything issued after it.
+  if constexpr (APPEND) asm("" : "+v"(new_k), "+v"(new_v));
   // ROWS: the group's own context is shared out between the sub-range waves (early groups are short)
   const int len_w = ROWS ? (ctx + p.sub * TS - 1) / (p.sub * TS) * TS : p.tps / p.sub;
   const int tw0 = t0 + sb * len_w;
@@ -215,6 +233,42 @@ paged_decode_kernel(const int32_t* a_bt, const int32_t* a_ctx, const void* a_q, 
   const char* kbase = static_cast<const char*>(p.kc);
   const char* vbase = static_cast<const char*>(p.vc);
   const uint32_t lane_off = (uint32_t)kvh * (uint32_t)p.s_head + dg * EPL;  // host checks it fits
+
+  // Append mode.  The new token sits at position ctx - 1 (a length beyond the launch's bound
+  // appends nothing), and of this workgroup only one wave per head reads that position: the one
+  // whose token range holds it, in the range's last pipeline step.  That wave never takes the row
+  // from the cache: it parks the new row's pieces in LDS now, puts them in place of whatever the
+  // loads of that step returned for the position, and stores them to the cache when its stream is
+  // done -- so no load of this launch depends on the store, and the store's way through the
+  // memory system is not on the path of the wave's loads (stores and loads of a wave complete in
+  // the order issued: a store ahead of the stream made every later wait of the wave wait for its
+  // acknowledgement too, 1.4 us on a 164 us launch).
+  bool append_here = false;
+  u32x4* s_new = nullptr;
+  if constexpr (APPEND) {
+    append_here = ctx_given == ctx && ctx - 1 >= tw0 && ctx - 1 < tw1;
+    s_new = reinterpret_cast<u32x4*>(smem + p.lds_new_off) + wave * 2 * LPT;
+    if (append_here && lane < LPT) {
+      s_new[dg] = new_k;
+      s_new[LPT + dg] = new_v;
+    }
+    __builtin_amdgcn_wave_barrier();   // (the wave's other lanes read these pieces later)
+  }
+  auto patch_step = [&](int step, u32x4 (&kb)[U], u32x4 (&vb)[U]) {
+    if constexpr (APPEND) {
+      if (append_here) {   // (wave-uniform; the pieces were written by this wave's own lanes)
+        const u32x4 nk = s_new[dg], nv = s_new[LPT + dg];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int t = min(tw0 + step * TS + u * TPL + tl, tw1 - 1);   // the row load_step fetched
+          if (t == ctx - 1) {
+            kb[u] = nk;
+            vb[u] = nv;
+          }
+        }
+      }
+    }
+  };
 
   auto load_step = [&](int step, u32x4 (&kb)[U], u32x4 (&vb)[U]) {
 #pragma unroll
@@ -273,11 +327,24 @@ paged_decode_kernel(const int32_t* a_bt, const int32_t* a_ctx, const void* a_q, 
   const int nsteps = tw1 > tw0 ? (tw1 - tw0 + TS - 1) / TS : 0;
   u32x4 ka[U], va[U], kb[U], vb[U];
   if (nsteps > 0) load_step(0, ka, va);
-  for (int s = 0; s < nsteps; s += 2) {
-    if (s + 1 < nsteps) load_step(s + 1, kb, vb);
-    compute_step(s, ka, va);
-    if (s + 2 < nsteps) load_step(s + 2, ka, va);
-    if (s + 1 < nsteps) compute_step(s + 1, kb, vb);
+  // (append mode: the position of the new row is the last one of its wave's range, so the step to
+  // patch is the range's last -- the one after which nothing is left to load)
+  if constexpr (APPEND) {
+    for (int s = 0; s < nsteps; s += 2) {
+      if (s + 1 < nsteps) load_step(s + 1, kb, vb);
+      else patch_step(s, ka, va);
+      compute_step(s, ka, va);
+      if (s + 2 < nsteps) load_step(s + 2, ka, va);
+      else if (s + 1 < nsteps) patch_step(s + 1, kb, vb);
+      if (s + 1 < nsteps) compute_step(s + 1, kb, vb);
+    }
+  } else {
+    for (int s = 0; s < nsteps; s += 2) {
+      if (s + 1 < nsteps) load_step(s + 1, kb, vb);
+      compute_step(s, ka, va);
+      if (s + 2 < nsteps) load_step(s + 2, ka, va);
+      if (s + 1 < nsteps) compute_step(s + 1, kb, vb);
+    }
   }
 
   // Merge the TPL lane groups of the wave (same dims, different tokens).
@@ -324,6 +391,18 @@ paged_decode_kernel(const int32_t* a_bt, const int32_t* a_ctx, const void* a_q, 
             acc[gi][e] = acc[gi][e] * fa + other[gi * kRec + dg * EPL + e] * fb;
         }
       }
+    }
+  }
+
+  if constexpr (APPEND) {
+    // the new row goes to the cache (behind the workgroup's barrier, which waits for a wave's stores)
+    if (append_here && lane < LPT) {
+      const int last = ctx - 1;
+      const int lb = block_of(last);
+      const uint64_t off = ((uint64_t)(uint32_t)s_bt[lb - lb0] * (uint64_t)p.s_blk +
+                            (uint32_t)(last - lb * p.block_size) * (uint32_t)p.s_tok + lane_off) * Tag::kBytes;
+      *reinterpret_cast<u32x4*>(const_cast<char*>(kbase) + off) = s_new[dg];
+      *reinterpret_cast<u32x4*>(const_cast<char*>(vbase) + off) = s_new[LPT + dg];
     }
   }
 
@@ -602,8 +681,12 @@ template <class Tag, int D, int G>
 int launch_decode(const DecodeParams& p, const DecodePlan& pl, hipStream_t stream) {
   const int64_t grid = (int64_t)p.B * p.nsplit * p.hgroups * p.qchunks;
   if (p.q_stride_seq >= (1LL << 31)) return fail(MI355_EINVAL, "paged_decode: q row stride out of range");
-  hipLaunchKernelGGL((paged_decode_kernel<Tag, D, G, steps_for_group(G), MI355_DECODE_NT != 0>), dim3((unsigned)grid),
-                     dim3(pl.nw * kWave), pl.lds_bytes, stream, MI355_DECODE_LEAD_ARGS(p), p);
+  if (p.k_new)
+    hipLaunchKernelGGL((paged_decode_kernel<Tag, D, G, steps_for_group(G), MI355_DECODE_NT != 0, false, true>),
+                       dim3((unsigned)grid), dim3(pl.nw * kWave), pl.lds_bytes, stream, MI355_DECODE_LEAD_ARGS(p), p);
+  else
+    hipLaunchKernelGGL((paged_decode_kernel<Tag, D, G, steps_for_group(G), MI355_DECODE_NT != 0>), dim3((unsigned)grid),
+                       dim3(pl.nw * kWave), pl.lds_bytes, stream, MI355_DECODE_LEAD_ARGS(p), p);
   if (int rc = check_launch("paged_decode_kernel")) return rc;
   if (p.nsplit > 1 && !p.counters) return launch_merge<Tag, D>(p, stream);
   return 0;
@@ -782,14 +865,48 @@ unsigned long long next_launch_tag() {
   return (counter.fetch_add(1, std::memory_order_relaxed) & ((1ull << 44) - 1)) | (0xFull << 44);
 }
 
-// Body of mi355_paged_decode; `what` names the entry point in error messages and `ws_limit_what`
-// says where the scratch comes from when it is too small.
+// The cache write of mi355_paged_decode_append as a launch of its own, for the shapes the
+// matrix-core decode kernel serves: thread = (sequence, kv head, 16-byte piece) stores that piece
+// of the sequence's new K and V row at position context - 1 of its block table.
+struct AppendParams {
+  char* kc;
+  char* vc;
+  const char* k;
+  const char* v;
+  const int32_t* bt;
+  const int32_t* ctx;
+  int64_t src_stride_seq, s_blk, s_head, s_tok;   // elements
+  int B, Hkv, lpt, ebytes, block_size, bs_shift, max_blocks, num_blocks, max_ctx;
+};
+
+__global__ void __launch_bounds__(256) kv_append_kernel(const AppendParams p) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int per_seq = p.Hkv * p.lpt;
+  if (idx >= (int64_t)p.B * per_seq) return;
+  const int b = (int)(idx / per_seq), rem = (int)(idx - (int64_t)b * per_seq);
+  const int h = rem / p.lpt, piece = rem - h * p.lpt;
+  const int ctx = p.ctx[b];
+  if (ctx < 1 || ctx > p.max_ctx) return;
+  const int last = ctx - 1;
+  const int lb = p.bs_shift >= 0 ? (last >> p.bs_shift) : (last / p.block_size);
+  const int id = min(max(p.bt[(int64_t)b * p.max_blocks + lb], 0), p.num_blocks - 1);
+  const int epl = 16 / p.ebytes;
+  const int64_t src = ((int64_t)b * p.src_stride_seq + (int64_t)h * p.lpt * epl + piece * epl) * p.ebytes;
+  const int64_t dst = ((int64_t)id * p.s_blk + (int64_t)h * p.s_head + (int64_t)(last - lb * p.block_size) * p.s_tok +
+                       piece * epl) * p.ebytes;
+  *reinterpret_cast<u32x4*>(p.kc + dst) = *reinterpret_cast<const u32x4*>(p.k + src);
+  *reinterpret_cast<u32x4*>(p.vc + dst) = *reinterpret_cast<const u32x4*>(p.v + src);
+}
+
+// Body of mi355_paged_decode; `what` names the entry point in error messages.  k_new / v_new
+// non-null: append mode (mi355_paged_decode_append), the caches are written before they are read.
 int paged_decode_impl(const char* what, void* out, const void* q, int64_t q_stride_seq, const void* k_cache,
                       const void* v_cache, const int32_t* block_tables, const int32_t* context_lens, int32_t B,
                       int32_t Hq, int32_t Hkv, int32_t D, int32_t block_size, int32_t max_blocks,
                       int32_t num_blocks, int32_t max_context, int64_t kv_stride_block, int64_t kv_stride_head,
                       int64_t kv_stride_tok, float scale, int32_t dtype, void* workspace, size_t workspace_bytes,
-                      void* stream) {
+                      void* stream, const void* k_new = nullptr, const void* v_new = nullptr,
+                      int64_t new_stride_seq = 0) {
   if (B == 0) return 0;
   if (!out || !q || !k_cache || !v_cache || !block_tables || !context_lens)
     return fail(MI355_EINVAL, "%s: null pointer argument", what);
@@ -862,6 +979,46 @@ int paged_decode_impl(const char* what, void* out, const void* q, int64_t q_stri
   p.seg_q0 = p.seg_len = p.seg_pos0 = nullptr;
   p.n_qt = p.tq = p.hgp_shift = p.max_q = 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (k_new) {
+    if (!v_new) return fail(MI355_EINVAL, "%s: null pointer argument", what);
+    if (new_stride_seq % epl || new_stride_seq < (int64_t)Hkv * D || (((uintptr_t)k_new | (uintptr_t)v_new) & 15))
+      return fail(MI355_EINVAL, "%s: new K/V rows must be 16-byte aligned, [B, Hkv, D]", what);
+    // per wave of the VALU kernel: the K and the V row of its head, parked in LDS
+    const size_t stash = (size_t)pl.nw * 2 * D * (dtype == MI355_F32 ? 4 : 2);
+    // The matrix-core kernel reads finished caches, and a workgroup's LDS has its limit: there
+    // the write goes first, as a launch of its own.
+    if (pl.mfma || pl.lds_bytes + stash > 64 * 1024) {
+      AppendParams ap;
+      ap.kc = static_cast<char*>(const_cast<void*>(k_cache));
+      ap.vc = static_cast<char*>(const_cast<void*>(v_cache));
+      ap.k = static_cast<const char*>(k_new);
+      ap.v = static_cast<const char*>(v_new);
+      ap.bt = block_tables;
+      ap.ctx = context_lens;
+      ap.src_stride_seq = new_stride_seq;
+      ap.s_blk = kv_stride_block;
+      ap.s_head = kv_stride_head;
+      ap.s_tok = kv_stride_tok;
+      ap.B = B;
+      ap.Hkv = Hkv;
+      ap.lpt = D / epl;
+      ap.ebytes = 16 / epl;
+      ap.block_size = block_size;
+      ap.bs_shift = p.bs_shift;
+      ap.max_blocks = max_blocks;
+      ap.num_blocks = num_blocks;
+      ap.max_ctx = max_context;
+      const int64_t threads = (int64_t)B * Hkv * ap.lpt;
+      hipLaunchKernelGGL(kv_append_kernel, dim3((unsigned)ceil_div64(threads, 256)), dim3(256), 0, s, ap);
+      if (int rc = check_launch("kv_append_kernel")) return rc;
+    } else {
+      p.k_new = k_new;
+      p.v_new = v_new;
+      p.new_stride_seq = new_stride_seq;
+      p.lds_new_off = (int)pl.lds_bytes;
+      pl.lds_bytes += stash;
+    }
+  }
   if (pl.mfma) return launch_gqa(p, pl, D, dtype, s);
   switch (dtype) {
     case MI355_F32: return dispatch_d<F32>(D, p, pl, s);
@@ -916,6 +1073,22 @@ extern "C" int mi355_paged_decode(void* out, const void* q, int64_t q_stride_seq
   return paged_decode_impl("paged_decode", out, q, q_stride_seq, k_cache, v_cache, block_tables, context_lens, B, Hq,
                            Hkv, D, block_size, max_blocks, num_blocks, max_context, kv_stride_block, kv_stride_head,
                            kv_stride_tok, scale, dtype, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mi355_paged_decode_append(void* out, const void* q, int64_t q_stride_seq, const void* k_new,
+                                         const void* v_new, int64_t new_stride_seq, void* k_cache, void* v_cache,
+                                         const int32_t* block_tables, const int32_t* context_lens, int32_t B,
+                                         int32_t Hq, int32_t Hkv, int32_t D, int32_t block_size,
+                                         int32_t max_blocks, int32_t num_blocks, int32_t max_context,
+                                         int64_t kv_stride_block, int64_t kv_stride_head, int64_t kv_stride_tok,
+                                         float scale, int32_t dtype, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
+  if (B == 0) return 0;
+  if (!k_new || !v_new) return fail(MI355_EINVAL, "paged_decode_append: null pointer argument");
+  return paged_decode_impl("paged_decode_append", out, q, q_stride_seq, k_cache, v_cache, block_tables, context_lens,
+                           B, Hq, Hkv, D, block_size, max_blocks, num_blocks, max_context, kv_stride_block,
+                           kv_stride_head, kv_stride_tok, scale, dtype, workspace, workspace_bytes, stream, k_new,
+                           v_new, new_stride_seq);
 }
 
 extern "C" int mi355_paged_decode_static(void* out, const void* q, int64_t q_stride_seq, const void* k_cache,

@@ -198,6 +198,63 @@ def paged_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
     return out
 
 
+def paged_decode_append(q: torch.Tensor, k_new: torch.Tensor, v_new: torch.Tensor, k_cache: torch.Tensor,
+                        v_cache: torch.Tensor, block_tables: torch.Tensor, context_lens: torch.Tensor,
+                        max_context: int, layout: str = 'NHSD', scale: Optional[float] = None,
+                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One decode step of an attention layer: k_new / v_new [B, Hkv, D] go to position
+    context_lens[b] - 1 of every sequence's cache, then q attends to the context_lens[b] cached
+    rows.  Same result (output and caches) as kv_write_slots at those slots followed by
+    paged_decode; where the VALU decode kernel runs, in one launch."""
+    dev = require_device(q, k_new, v_new, k_cache, v_cache, block_tables, context_lens)
+    lib = _lib.load()
+    if q.dim() != 3 or q.stride(2) != 1 or q.stride(1) != q.shape[2]:
+        q = q.contiguous()
+    B, Hq, D = q.shape
+    g = _kv_geometry(k_cache, layout)
+    if tuple(v_cache.shape) != tuple(k_cache.shape) or _kv_geometry(v_cache, layout) != g:
+        raise ValueError("k_cache and v_cache must share shape and strides")
+    if not (k_cache.dtype == v_cache.dtype == k_new.dtype == v_new.dtype == q.dtype):
+        raise TypeError("query, new rows and KV cache dtypes differ")
+    if g['head_dim'] != D:
+        raise ValueError(f"head_dim mismatch: q {D}, cache {g['head_dim']}")
+
+    def rows(t):
+        if t.dim() != 3 or t.stride(2) != 1 or t.stride(1) != t.shape[2]:
+            t = t.contiguous()
+        return t
+
+    k_new, v_new = rows(k_new), rows(v_new)
+    if _stride(v_new, 0) != _stride(k_new, 0):
+        k_new, v_new = k_new.contiguous(), v_new.contiguous()
+    if tuple(k_new.shape) != (B, g['heads'], D) or tuple(v_new.shape) != (B, g['heads'], D):
+        raise ValueError("k_new / v_new must be [B, kv_heads, head_dim] matching the cache")
+    if block_tables.dtype != torch.int32 or context_lens.dtype != torch.int32:
+        raise TypeError("block_tables and context_lens must be int32")
+    block_tables = block_tables.contiguous()
+    context_lens = context_lens.contiguous()
+    if block_tables.dim() != 2 or block_tables.shape[0] != B or context_lens.numel() != B:
+        raise ValueError("block_tables must be [B, max_blocks] and context_lens [B]")
+    out = _checked_out(out, (B, Hq, D), q.dtype, dev)
+    code = dtype_code(q)
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    max_context = min(int(max_context), block_tables.shape[1] * g['block_size'])
+    with _on(dev):
+        stream = _stream(dev)
+        need = lib.mi355_paged_decode_workspace_bytes(B, Hq, g['heads'], D, g['block_size'],
+                                                      max_context, code)
+        ws, ws_bytes = _workspace(dev, need, stream)
+        rc = lib.mi355_paged_decode_append(
+            out.data_ptr(), q.data_ptr(), _stride(q, 0), k_new.data_ptr(), v_new.data_ptr(), _stride(k_new, 0),
+            k_cache.data_ptr(), v_cache.data_ptr(), block_tables.data_ptr(), context_lens.data_ptr(),
+            B, Hq, g['heads'], D, g['block_size'], block_tables.shape[1], g['num_blocks'], max_context,
+            g['s_block'], g['s_head'], g['s_tok'], float(scale), code,
+            ws.data_ptr() if ws is not None else None, ws_bytes, stream)
+    _lib.check(rc, 'mi355_paged_decode_append')
+    return out
+
+
 def kv_write_slots(k_cache: torch.Tensor, v_cache: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
                    slots: torch.Tensor, layout: str = 'NHSD') -> None:
     """cache[slot // BS, :, slot % BS, :] = row, for T rows; k, v [T, Hkv, D]; slots [T] int64."""
