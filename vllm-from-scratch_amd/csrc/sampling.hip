@@ -43,6 +43,39 @@ __device__ __forceinline__ int wave_reduce(int v, Op op) {
             op(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
+// Inclusive prefix sum of a 64-bit value over the lanes of a wave (lane l: lanes 0 .. l) by DPP
+// row shifts and row broadcasts: both halves are moved with the same control word (lanes without
+// a source get 0) and added as one 64-bit integer, so carries are kept.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_move_u64(unsigned long long v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, ROW_MASK, 0xf, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, ROW_MASK, 0xf, false);
+  return ((unsigned long long)hi << 32) | lo;
+}
+// The same for a float (lane l: v of lanes 0 .. l, added in the fixed order of the six steps).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_prefix_sum(float v) {
+  v += dpp_move_f<0x111, 0xf>(v);
+  v += dpp_move_f<0x112, 0xf>(v);
+  v += dpp_move_f<0x114, 0xf>(v);
+  v += dpp_move_f<0x118, 0xf>(v);
+  v += dpp_move_f<0x142, 0xa>(v);
+  v += dpp_move_f<0x143, 0xc>(v);
+  return v;
+}
+__device__ __forceinline__ unsigned long long wave_prefix_sum_u64(unsigned long long v) {
+  v += dpp_move_u64<0x111, 0xf>(v);   // row_shr:1
+  v += dpp_move_u64<0x112, 0xf>(v);   // row_shr:2
+  v += dpp_move_u64<0x114, 0xf>(v);   // row_shr:4
+  v += dpp_move_u64<0x118, 0xf>(v);   // row_shr:8   -> prefix within each row of 16
+  v += dpp_move_u64<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+  v += dpp_move_u64<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
 // Workgroup-wide reductions through a two-slot LDS exchange: call n uses slot n & 1, so one
 // barrier per call is enough (a wave can be at most one call ahead of the slowest reader).
 struct Exchange {
@@ -201,6 +234,18 @@ struct FC {  // (probability mass, count) pair reduced together
   int c;
 };
 
+// SAMPLER_TIMING (side builds only): thread 0 of every workgroup writes the shader clock at the
+// phase boundaries of sample_kernel into out_probs (as 64-bit words, 32 per row) instead of
+// probabilities.
+#ifdef SAMPLER_TIMING
+#define STAMP(n)                                                                                     \
+  do {                                                                                               \
+    if (threadIdx.x == 0 && p.out_probs)                                                             \
+      reinterpret_cast<unsigned long long*>(p.out_probs)[(size_t)blockIdx.x * 32 + (n)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define STAMP(n) do { } while (0)
+#endif
 #ifndef SAMPLER_LEAN_MATH
 #define SAMPLER_LEAN_MATH 1
 #endif
@@ -265,20 +310,22 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
   __shared__ int s_tie_n;
   __shared__ float s_walk[VPT > 0 ? VPT : 1];   // the picking thread's elements, handed to wave 0
   __shared__ float s_walk_base;
+  __shared__ float s_uniform;
   int slot = 0;
   const int tid = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
+  STAMP(0);
   const int lane = tid & 63, wave = tid >> 6;
+  // The row's one random number, by one thread while the row's first loads are in the air (its ten
+  // rounds of 64-bit products otherwise sit in every thread's way right before the draw); read back
+  // behind the barriers of the reductions below.
+  auto draw_uniform = [&]() {
+    if (tid == 0) s_uniform = philox_uniform(p.seed, p.offset + (uint64_t)b);
+  };
   // Wave 0 finds the first of the picker's elements (s_walk, running sum starting at s_walk_base)
   // whose running sum passes the target, with a prefix scan, and writes its index.
   auto walk_pick = [&](int picker, float target) {
     const float q = lane < VPT ? s_walk[lane < VPT ? lane : 0] : 0.f;
-    float run = q;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const float o = __shfl_up(run, off);
-      if (lane >= off) run += o;
-    }
-    run += s_walk_base;
+    const float run = wave_prefix_sum(q) + s_walk_base;
     const unsigned long long hit = __ballot(q > 0.f && run > target);
     const unsigned long long any = __ballot(q > 0.f);          // not empty: the picker's mass is > 0
     const int j = hit ? __ffsll((long long)hit) - 1 : 63 - __clzll((long long)any);
@@ -293,7 +340,6 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
   auto addf = [](float a, float c) { return a + c; };
   auto addi = [](int a, int c) { return a + c; };
   auto maxi = [](int a, int c) { return max(a, c); };
-  auto mini = [](int a, int c) { return min(a, c); };
 
   // p = softmax(x / T): the division comes first, as in the reference.  Register-resident
   // rows are divided and exponentiated exactly once.
@@ -301,6 +347,8 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
   float pr[NR];
   float mx = -__builtin_inff(), z = 0.f;
   const float inv_t = 1.0f / temp;
+  const bool unit_temp = temp == 1.0f;   // x / 1 is x, exactly
+  auto by_temp = [&](float x) { return unit_temp ? x : div_shared(x, temp, inv_t); };
   // Rows that do not fit the registers are streamed from memory on every pass: fn(logit, index)
   // for the thread's elements tid, tid + nt, ... in that order, kStreamU loads in flight per thread
   // (the index is clamped instead of branching around the load, so that the loads of a group
@@ -348,6 +396,7 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
       for (int k = 0; k < VPT / EPL; ++k)
         raw[k] = __builtin_nontemporal_load(
             reinterpret_cast<const u32x4*>(row + (int64_t)min(k * nt + tid, nvec - 1) * EPL));
+      draw_uniform();
 #pragma unroll
       for (int k = 0; k < VPT / EPL; ++k) {
         float f[EPL];
@@ -358,13 +407,19 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
     } else {
 #pragma unroll
       for (int j = 0; j < VPT; ++j) pr[j] = Tag::to_float(row[min(j * nt + tid, vocab - 1)]);
+      draw_uniform();
+    }
+    if (!unit_temp) {   // (wave-uniform: a row at temperature 1 skips 32 divisions per thread)
+#pragma unroll
+      for (int j = 0; j < VPT; ++j) pr[j] = div_shared(pr[j], temp, inv_t);
     }
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
-      pr[j] = (eidx(j) < vocab) ? div_shared(pr[j], temp, inv_t) : -__builtin_inff();
+      pr[j] = (eidx(j) < vocab) ? pr[j] : -__builtin_inff();
       mx = fmaxf(mx, pr[j]);
     }
     mx = block_reduce(mx, fmaxop, xch, slot);
+    STAMP(1);
     // A row without a cut whose distribution nobody asked for only needs its draw: weights
     // e = exp2((x/T - max) log2 e) (a plain exp2: the extra digits of exp_nonpos pin the kept set of
     // a cut, here they would only move a draw by an ulp of the target), no division by their sum --
@@ -376,12 +431,7 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
         pr[j] = __builtin_amdgcn_exp2f((pr[j] - mx) * 1.44269504088896340736f);   // absent elements: 0
         mine += pr[j];
       }
-      float incl = mine;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const float o = __shfl_up(incl, off);
-        if (lane >= off) incl += o;
-      }
+      const float incl = wave_prefix_sum(mine);
       if (lane == 63) s_scan[wave] = incl;
       if (tid == 0) s_pick = 0x7fffffff;
       __syncthreads();
@@ -393,7 +443,7 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
         total += v;
         base += w < wave ? v : 0.f;
       }
-      const float target = philox_uniform(p.seed, p.offset + (uint64_t)b) * total;
+      const float target = s_uniform * total;
       const float excl = base + incl - mine;
       if (mine > 0.f && excl <= target && target < excl + mine) atomicMin(&s_pick, tid);
       __syncthreads();
@@ -422,16 +472,18 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
     }
     z = block_reduce(z, addf, xch, slot);
     const float inv_z = 1.0f / z;
+    STAMP(2);
 #pragma unroll
     for (int j = 0; j < VPT; ++j) pr[j] = (eidx(j) < vocab) ? div_shared(pr[j], z, inv_z) : -1.0f;   // -1 marks "no element"
   } else {
-    stream_row([&](float x, int) { mx = fmaxf(mx, div_shared(x, temp, inv_t)); });
+    draw_uniform();
+    stream_row([&](float x, int) { mx = fmaxf(mx, by_temp(x)); });
     mx = block_reduce(mx, fmaxop, xch, slot);
-    stream_row([&](float x, int) { z += exp_nonpos(div_shared(x, temp, inv_t) - mx); });
+    stream_row([&](float x, int) { z += exp_nonpos(by_temp(x) - mx); });
     z = block_reduce(z, addf, xch, slot);
   }
   const float inv_z_row = 1.0f / z;
-  auto prob_of = [&](float x) { return div_shared(exp_nonpos(div_shared(x, temp, inv_t) - mx), z, inv_z_row); };
+  auto prob_of = [&](float x) { return div_shared(exp_nonpos(by_temp(x) - mx), z, inv_z_row); };
   // Visits every element this thread owns: fn(probability, index).
   auto for_each = [&](auto fn) {
     if constexpr (VPT > 0) {
@@ -445,7 +497,7 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
 
   // Cut: elements with probability > vstar are kept, and of those equal to vstar
   // the ones with index < tie_end.  Default keeps everything.
-  float vstar = -1.0f, kept_mass;
+  float vstar = -0.5f, kept_mass;   // (below every probability, above the -1 that marks "no element")
   int tie_end = vocab;
   const bool filter = tp < 1.0f || tk > 0;
   if (!filter) {
@@ -471,6 +523,13 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
     const bool use_p = tp < 1.0f;
     auto ok = [&](float mass, int count) { return (!use_p || mass < tp) && count < kk; };
     constexpr unsigned long long kMassMask = (1ull << 41) - 1;
+    // mass field (41 bits, units of 2^-40) -> float, correctly rounded: the upper 24 bits and the
+    // lower 17 are each exact as floats and their sum is rounded once -- what the generic 64-bit
+    // conversion returns, in a third of its instructions.
+    auto mass_of = [&](unsigned long long packed) {
+      const unsigned long long m = packed & kMassMask;
+      return __builtin_fmaf((float)(uint32_t)(m >> 17), 131072.0f, (float)((uint32_t)m & 0x1FFFFu)) * 0x1p-40f;
+    };
     constexpr int kLevelShift[3] = {kHistShift, 8, 0};
     constexpr int kLevelBits[3] = {11, 11, 8};        // level 0: bit 31 is the sign (0), keys < kHistBins
     static_assert(kHistShift == 19 && kHistBins == 2048, "the three fields must tile the 32 bits");
@@ -491,6 +550,7 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
       const int shift = kLevelShift[L], nbins = 1 << kLevelBits[L];
       for (int i = tid; i < nbins; i += nt) s_hist[i] = 0ull;
       __syncthreads();
+      STAMP(3 + 5 * L);
       if (L > 0 && listed >= 0) {
         for (int i = tid; i < listed; i += nt) {
           const float q = s_list[i];
@@ -502,51 +562,69 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
         });
       }
       __syncthreads();
+      STAMP(4 + 5 * L);
       {
         // Every thread owns nbins / nt consecutive bins (at least one; threads past the last bin
-        // idle): suffix sums over the threads above it -- within the wave by shuffles, across waves
-        // through LDS -- then a walk down its own bins.  `run` = everything above the bin.  Passing
-        // bins form an upper range, so the cut bin is the lowest one that passes.  (One wave
-        // scanning all 2048 bins alone, 32 per lane, took 3-4 us of a level's 6-9.)
+        // idle), thread 0 the highest ones: what lies above a thread's bins is then a prefix sum
+        // over the threads before it -- within the wave by DPP shifts (no LDS round trips), across
+        // waves through LDS.  `run` = everything above the bin.  Passing bins form an upper range,
+        // and whether a bin's lower neighbour passes follows from the bin's own content, so the
+        // one thread that owns the lowest passing bin sees that by itself and publishes the cut:
+        // no workgroup-wide minimum.  (One wave scanning all 2048 bins alone, 32 per lane, took
+        // 3-4 us of a level's 6-9; suffix sums by wave shuffles and a minimum over the workgroup,
+        // 2.3 us per level.)
         const int bpt = nbins >= nt ? nbins / nt : 1;
-        const int first = tid * bpt;
-        const bool has = first < nbins;
+        const int hi_bin = nbins - 1 - tid * bpt;          // this thread's highest bin; its others follow downwards
+        const bool has = tid * bpt < nbins;
         unsigned long long own = 0ull;
         if (has)
-          for (int i = 0; i < bpt; ++i) own += s_hist[first + i];
-        unsigned long long incl = own;    // inclusive suffix scan: lanes >= l of this wave
-#pragma unroll
-        for (int off = 1; off < kWave; off <<= 1) {
-          const unsigned long long o = __shfl_down(incl, off);
-          if (lane + off < kWave) incl += o;
-        }
-        if (lane == 0) s_wsum[wave] = incl;
+          for (int i = 0; i < bpt; ++i) own += s_hist[hi_bin - i];
+        const unsigned long long incl = wave_prefix_sum_u64(own);   // lanes <= this one
+        if (lane == kWave - 1) s_wsum[wave] = incl;
+        if (tid == 0) s_cutbin = -1;
         __syncthreads();
-        unsigned long long above = acc + (incl - own);
-        for (int w = wave + 1; w < (nt >> 6); ++w) above += s_wsum[w];
-        unsigned long long run = above;
-        int best = 0x7fffffff, top = -1;
-        if (has)
-          for (int i = bpt - 1; i >= 0; --i) {
-            const unsigned long long h = s_hist[first + i];
-            if (ok((float)(run & kMassMask) * 0x1p-40f, (int)(run >> 41))) best = first + i;
-            if (h != 0ull && top < 0) top = first + i;
-            run += h;
+        unsigned long long run = acc + (incl - own);
+#pragma unroll
+        for (int w = 0; w < kMaxWaves; ++w) {              // (all reads issue together)
+          const unsigned long long v = s_wsum[w < (nt >> 6) ? w : 0];
+          run += w < wave ? v : 0ull;
+        }
+        if (has) {
+          bool pass_here = ok(mass_of(run), (int)(run >> 41));
+          for (int i = 0; i < bpt; ++i) {
+            const int bin = hi_bin - i;
+            const unsigned long long h = s_hist[bin];
+            const unsigned long long below = run + h;      // what lies above the next lower bin
+            const bool pass_below = bin > 0 && ok(mass_of(below), (int)(below >> 41));
+            if (pass_here && !pass_below) {                // the lowest passing bin
+              s_cutbin = bin;
+              s_above = run;
+              s_cutcount = (int)(h >> 41);
+            }
+            pass_here = pass_below;
+            run = below;
           }
-        int sel = block_reduce(best, mini, xch, slot);
-        if (sel == 0x7fffffff)   // nothing passes (top_p <= 0): the largest value alone survives -> follow the top bin
-          sel = max(block_reduce(top, maxi, xch, slot), 0);
-        if (has && sel >= first && sel < first + bpt) {
-          unsigned long long r = above;
-          for (int bin = first + bpt - 1; bin > sel; --bin) r += s_hist[bin];
-          s_cutbin = sel;
-          s_above = r;
-          s_cutcount = (int)(s_hist[sel] >> 41);
+        }
+        __syncthreads();
+        STAMP(5 + 5 * L);
+        if (s_cutbin < 0) {
+          // nothing passes (top_p <= 0): the largest value alone survives -> follow the highest bin in use
+          int top = -1;
+          if (has)
+            for (int i = bpt - 1; i >= 0; --i) top = s_hist[hi_bin - i] != 0ull ? hi_bin - i : top;
+          const int sel = max(block_reduce(top, maxi, xch, slot), 0);
+          if (has && sel <= hi_bin && sel > hi_bin - bpt) {
+            unsigned long long r = acc;                    // everything above the bin: this level's bins above it are empty
+            s_cutbin = sel;
+            s_above = r;
+            s_cutcount = (int)(s_hist[sel] >> 41);
+          }
         }
       }
       __syncthreads();
       prefix = (prefix << kLevelBits[L]) | (uint32_t)s_cutbin;
       acc = s_above;
+      STAMP(6 + 5 * L);
       if (L == 0 && s_cutcount <= kListCap) {     // (the bin's exact population: the list cannot overflow)
         listed = s_cutcount;
         if (tid == 0) s_list_n = 0;
@@ -556,10 +634,12 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
         });
         // (the next level's barrier after zeroing the bins orders these writes before its reads)
       }
+      STAMP(7 + 5 * L);
     }
+    STAMP(18);
     vstar = __builtin_bit_cast(float, prefix);
     const int ties = s_cutcount;
-    const FC a = {(float)(acc & kMassMask) * 0x1p-40f, (int)(acc >> 41)};   // strictly above vstar
+    const FC a = {mass_of(acc), (int)(acc >> 41)};   // strictly above vstar
     // Of the `ties` copies of vstar, copy j (0-based, lowest index first -- the stable descending order)
     // is kept iff mass_above + j * v < top_p and count_above + j < k.
     int keep = ties;
@@ -609,25 +689,50 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
     }
     kept_mass = a.f + (float)keep * vstar;
   }
+  STAMP(19);
+  // Kept: q > vstar, and of the copies of vstar those with index < tie_end.  Almost always either all
+  // copies stay (q >= vstar) or none does (q > vstar); the choice is the same for the whole row, and
+  // the passes below run over 32 elements per thread, so they take the one-comparison forms.
+  const int keep_mode = tie_end >= vocab ? 1 : tie_end <= 0 ? 0 : 2;
   auto is_kept = [&](float q, int i) { return q > vstar || (q == vstar && i < tie_end); };
+  // kept ? value : 0 for the thread's j-th register-resident element, one comparison in modes 0 and 1
+  // (vstar > -1: the "no element" marker fails both)
+  auto kept_value = [&](int j, int mode) {
+    const float q = pr[j < NR ? j : 0];
+    if (mode == 1) return q >= vstar ? q : 0.f;
+    if (mode == 0) return q > vstar ? q : 0.f;
+    return (q >= 0.f && is_kept(q, eidx(j))) ? q : 0.f;
+  };
 
+#ifndef SAMPLER_TIMING
   if (p.out_probs) {
     float* dst = p.out_probs + (int64_t)b * vocab;
     for_each([&](float q, int i) { dst[i] = is_kept(q, i) ? q / kept_mass : 0.f; });
   }
+#endif
 
   // One draw.  Kept mass is walked thread by thread (any fixed order gives the
   // same distribution): exclusive scan of per-thread kept sums, the thread whose
   // interval contains the target walks its own elements.
-  const float target = philox_uniform(p.seed, p.offset + (uint64_t)b) * kept_mass;
+  STAMP(20);
+  const float target = s_uniform * kept_mass;
   float mine = 0.f;
-  for_each([&](float q, int i) { mine += is_kept(q, i) ? q : 0.f; });
-  float incl = mine;
+  if constexpr (VPT > 0) {
+    if (keep_mode == 1) {
 #pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const float o = __shfl_up(incl, off);
-    if (lane >= off) incl += o;
+      for (int j = 0; j < VPT; ++j) mine += kept_value(j, 1);
+    } else if (keep_mode == 0) {
+#pragma unroll
+      for (int j = 0; j < VPT; ++j) mine += kept_value(j, 0);
+    } else {
+#pragma unroll
+      for (int j = 0; j < VPT; ++j) mine += kept_value(j, 2);
+    }
+  } else {
+    for_each([&](float q, int i) { mine += is_kept(q, i) ? q : 0.f; });
   }
+  const float incl = wave_prefix_sum(mine);
+  STAMP(21);
   if (lane == 63) s_scan[wave] = incl;
   if (tid == 0) s_pick = 0x7fffffff;
   __syncthreads();
@@ -637,6 +742,7 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
   const float excl = base + incl - mine;
   if (mine > 0.f && excl <= target && target < excl + mine) atomicMin(&s_pick, tid);
   __syncthreads();
+  STAMP(22);
   const int picker = s_pick;
   if (picker == 0x7fffffff) {
     // rounding pushed the target past the walked total (or between two threads' intervals): the
@@ -652,11 +758,20 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
     // whose running sum passes the target with a prefix scan (one thread walking its 32 registers
     // alone costs more than the rest of the draw).
     if (tid == picker) {
+      if (keep_mode == 1) {
 #pragma unroll
-      for (int j = 0; j < VPT; ++j) s_walk[j] = (pr[j] >= 0.f && is_kept(pr[j], eidx(j))) ? pr[j] : 0.f;
+        for (int j = 0; j < VPT; ++j) s_walk[j] = kept_value(j, 1);
+      } else if (keep_mode == 0) {
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) s_walk[j] = kept_value(j, 0);
+      } else {
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) s_walk[j] = kept_value(j, 2);
+      }
       s_walk_base = excl;
     }
     __syncthreads();
+    STAMP(23);
     if (wave == 0) walk_pick(picker, target);
   } else {
     if (tid == picker) {
