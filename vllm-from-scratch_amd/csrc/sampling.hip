@@ -302,6 +302,7 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
   __shared__ unsigned long long s_above;
   __shared__ unsigned long long s_wsum[kMaxWaves];
   __shared__ int s_cutbin, s_cutcount;
+  __shared__ uint32_t s_cutbits;
   constexpr int kListCap = 4096;
   __shared__ float s_list[kListCap];
   __shared__ int s_list_n;
@@ -545,8 +546,59 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
       atomicAdd(&s_hist[(__builtin_bit_cast(uint32_t, q) >> shift) & (uint32_t)(nbins - 1)],
                 (1ull << 41) + (unsigned long long)(q * 1099511627776.0f));   // count | q * 2^40
     };
+    // A cut bin of up to 64 values (the usual case under a top-k limit: a handful) is finished by
+    // wave 0 alone, one value per lane, in place of the two lower levels and their ten workgroup
+    // phases.  What lies above a lane's value is summed exactly as the bins would (count | mass
+    // in one 64-bit word), over one broadcast per listed value.  The passing bit patterns of the
+    // bin's range form an upper range that can only start at the range's lowest pattern or at one
+    // of the listed values -- between two listed values nothing changes -- so the lowest passing
+    // one of those is the pattern the radix levels would end on; when nothing passes (top_p <= 0)
+    // both follow the largest value.
+    constexpr int kWaveFinishMax = 64;
+    auto finish_in_wave0 = [&]() {
+      __syncthreads();                       // the list is complete
+      if (wave == 0) {
+        const bool live = lane < listed;
+        const float q = live ? s_list[live ? lane : 0] : 0.f;
+        const uint32_t vb = __builtin_bit_cast(uint32_t, q);
+        const unsigned long long w = live ? (1ull << 41) + (unsigned long long)(q * 1099511627776.0f) : 0ull;
+        const uint32_t lo = prefix << kHistShift;
+        unsigned long long above_own = acc, above_lo = acc;
+        for (int j = 0; j < listed; ++j) {   // (wave-uniform trip count)
+          const uint32_t vj = (uint32_t)__builtin_amdgcn_readlane((int)vb, j);
+          const unsigned long long wj =
+              ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), j) << 32) |
+              (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, j);
+          above_own += vj > vb ? wj : 0ull;
+          above_lo += vj > lo ? wj : 0ull;
+        }
+        auto passes = [&](unsigned long long a) { return ok(mass_of(a), (int)(a >> 41)); };
+        uint32_t v = lo;
+        unsigned long long a_final = above_lo;
+        if (!passes(above_lo) && listed > 0) {
+          const bool pass_own = live && passes(above_own);
+          int cand = wave_reduce(pass_own ? (int)vb : 0x7fffffff, [](int x, int y) { return min(x, y); });
+          if (cand == 0x7fffffff) cand = wave_reduce(live ? (int)vb : 0, maxi);   // nothing passes: the largest value
+          v = (uint32_t)cand;
+          const unsigned long long holders = __ballot(live && vb == v);           // not empty: v is a listed value
+          const int src = __ffsll((long long)holders) - 1;
+          a_final = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(above_own >> 32), src) << 32) |
+                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)above_own, src);
+        }
+        const int same = __popcll(__ballot(live && vb == v));
+        if (lane == 0) {
+          s_cutbits = v;
+          s_above = a_final;
+          s_cutcount = same;
+        }
+      }
+      __syncthreads();
+      prefix = s_cutbits;
+      acc = s_above;
+    };
 #pragma unroll
     for (int L = 0; L < 3; ++L) {
+      if (L > 0 && listed >= 0 && listed <= kWaveFinishMax) continue;   // (finished below, by wave 0)
       const int shift = kLevelShift[L], nbins = 1 << kLevelBits[L];
       for (int i = tid; i < nbins; i += nt) s_hist[i] = 0ull;
       __syncthreads();
@@ -636,6 +688,7 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
       }
       STAMP(7 + 5 * L);
     }
+    if (listed >= 0 && listed <= kWaveFinishMax) finish_in_wave0();
     STAMP(18);
     vstar = __builtin_bit_cast(float, prefix);
     const int ties = s_cutcount;
