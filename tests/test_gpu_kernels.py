@@ -999,6 +999,39 @@ def test_sampling_ties_at_the_cut_keep_lowest_indices(ops, device, vocab):
         assert got_kept[int(ids[b])]
 
 
+@pytest.mark.parametrize('vocab', [1500, 20000, 32000])
+def test_sampling_top_k_sizes_around_the_bounded_tally(ops, device, vocab):
+    """Top-k limits on both sides of the size up to which the kernel tallies only the values above a
+    lower bound of the k-th largest (k' = ceil(k / waves) <= 8 per wave): exactly k tokens stay, the
+    largest ones, with and without a nucleus cut on top -- also on rows whose large values all sit
+    in a few threads' elements, repeat many times, or are all equal."""
+    rng = np.random.default_rng(vocab + 9)
+    rows, temps, top_ps, top_ks = [], [], [], []
+    spread = (rng.standard_normal(vocab) * 2).astype(np.float32)
+    clustered = (rng.standard_normal(vocab) * 0.5).astype(np.float32)
+    clustered[100:140] += 9.0                                       # the 40 largest values are neighbours in memory
+    repeats = rng.integers(0, 6, size=vocab).astype(np.float32)      # six distinct values, thousands of copies each
+    for k in (1, 2, 16, 17, 50, 128, 129, 400):
+        for x, p in ((spread, 1.0), (clustered, 1.0), (repeats, 1.0), (spread, 0.8)):
+            rows.append(x); temps.append(1.0 if p == 1.0 else 0.8); top_ps.append(p); top_ks.append(k)
+    rows.append(np.zeros(vocab, dtype=np.float32)); temps.append(1.0); top_ps.append(1.0); top_ks.append(50)
+    logits = np.stack(rows)
+    ids, probs = ops.sample_topk_topp(torch.from_numpy(logits).to(device), torch.tensor(temps, device=device),
+                                      torch.tensor(top_ps, device=device),
+                                      torch.tensor(top_ks, dtype=torch.int32, device=device), seed=11, return_probs=True)
+    probs = probs.cpu().numpy()
+    for b in range(len(rows)):
+        want, kept = orc.nucleus_probs(logits[b], temps[b], top_ps[b], top_ks[b])
+        got_kept = probs[b] > 0
+        if top_ps[b] == 1.0:
+            assert int(got_kept.sum()) == min(top_ks[b], vocab), f"row {b} (k={top_ks[b]}): {got_kept.sum()} tokens kept"
+            assert np.array_equal(got_kept, kept), f"row {b} (k={top_ks[b]})"
+            np.testing.assert_allclose(probs[b], want, rtol=2e-4, atol=1e-9)
+        else:
+            assert len(np.nonzero(got_kept != kept)[0]) <= 1
+        assert got_kept[int(ids[b])]
+
+
 def test_sampling_distribution(ops, device):
     """Draws follow the filtered distribution (chi-square style bound on 20k draws)."""
     vocab, n = 16, 20000

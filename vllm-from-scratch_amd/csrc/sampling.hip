@@ -303,6 +303,7 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
   __shared__ unsigned long long s_wsum[kMaxWaves];
   __shared__ int s_cutbin, s_cutcount;
   __shared__ uint32_t s_cutbits;
+  __shared__ float s_wbound[kMaxWaves];
   constexpr int kListCap = 4096;
   __shared__ float s_list[kListCap];
   __shared__ int s_list_n;
@@ -542,6 +543,33 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
     // register-resident row that is 32 compares per thread per level, for a streamed row another
     // trip through memory).
     int listed = -1;                   // >= 0: the candidates are s_list[0 .. listed)
+    // Under a top-k limit nothing below the k-th largest probability matters: not for the cut, not
+    // for what lies above it.  A lower bound on that value lets the passes below skip most of the
+    // row, and the first level's 32 LDS atomics per thread are its largest single cost.  Every
+    // wave takes the k'-th largest of its lanes' largest values, k' = ceil(k / waves): at least k'
+    // different elements of the row are >= it, so the smallest of the waves' values has at least k
+    // elements at or above it and cannot exceed the k-th largest.  Bins below the bound's then stay
+    // empty, but everything tallied lies above them -- at least k elements -- so they fail the count
+    // test as they would with the whole row in; from the bound's bin upwards nothing changes.
+    float tally_from = 0.f;
+    bool bounded = false;
+    if constexpr (VPT > 0) {
+      const int nw = nt >> 6;
+      const int per_wave = tk > 0 ? (tk + nw - 1) / nw : 0;
+      bounded = per_wave >= 1 && per_wave <= 8;          // (wave-uniform; larger k: the whole row is tallied)
+      if (bounded) {
+        float top = -1.0f;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) top = fmaxf(top, pr[j]);
+        float kth = -1.0f;
+        for (int r = 0; r < per_wave; ++r) {
+          kth = wave_reduce(top, fmaxop);
+          const unsigned long long holders = __ballot(top == kth);
+          if (lane == __ffsll((long long)holders) - 1) top = -2.0f;   // one lane gives its value up per round
+        }
+        if (lane == 0) s_wbound[wave] = kth;             // (read behind the first level's first barrier)
+      }
+    }
     auto tally = [&](float q, int shift, int nbins) {
       atomicAdd(&s_hist[(__builtin_bit_cast(uint32_t, q) >> shift) & (uint32_t)(nbins - 1)],
                 (1ull << 41) + (unsigned long long)(q * 1099511627776.0f));   // count | q * 2^40
@@ -603,6 +631,12 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
       for (int i = tid; i < nbins; i += nt) s_hist[i] = 0ull;
       __syncthreads();
       STAMP(3 + 5 * L);
+      if (L == 0 && bounded) {
+        float lowest = s_wbound[0];
+#pragma unroll
+        for (int w = 1; w < kMaxWaves; ++w) lowest = fminf(lowest, s_wbound[w < (nt >> 6) ? w : 0]);
+        tally_from = fmaxf(lowest, 0.f);                 // (a wave without k' values reports -1: no bound)
+      }
       if (L > 0 && listed >= 0) {
         for (int i = tid; i < listed; i += nt) {
           const float q = s_list[i];
@@ -610,7 +644,8 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
         }
       } else {
         for_each([&](float q, int) {
-          if (L == 0 || (__builtin_bit_cast(uint32_t, q) >> (shift + kLevelBits[L])) == prefix) tally(q, shift, nbins);
+          if (q >= tally_from && (L == 0 || (__builtin_bit_cast(uint32_t, q) >> (shift + kLevelBits[L])) == prefix))
+            tally(q, shift, nbins);
         });
       }
       __syncthreads();
@@ -682,7 +717,8 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
         if (tid == 0) s_list_n = 0;
         __syncthreads();
         for_each([&](float q, int) {
-          if ((__builtin_bit_cast(uint32_t, q) >> kHistShift) == prefix) s_list[atomicAdd(&s_list_n, 1)] = q;
+          if (q >= tally_from && (__builtin_bit_cast(uint32_t, q) >> kHistShift) == prefix)
+            s_list[atomicAdd(&s_list_n, 1)] = q;
         });
         // (the next level's barrier after zeroing the bins orders these writes before its reads)
       }
