@@ -1049,6 +1049,40 @@ def test_sampling_distribution(ops, device):
     assert not np.array_equal(ids, other)
 
 
+@pytest.mark.parametrize('dtype,vocab', [(torch.float32, 40000), (torch.float32, 70001), (torch.bfloat16, 131072)])
+def test_sampling_streamed_rows_without_a_cut_follow_the_softmax(ops, device, dtype, vocab):
+    """Rows longer than the registers hold, no cut, no distribution asked for (one trip through
+    memory): 10 tokens carry the mass, at positions spread over the row; drawn frequencies must match
+    their softmax at the given temperature, and masked (-inf) or NaN entries are never drawn."""
+    rng = np.random.default_rng(vocab)
+    B, calls, T = 256, 24, 0.8
+    heavy = rng.choice(vocab, size=10, replace=False)
+    heavy[0], heavy[1] = 0, vocab - 1                          # the row's first and last element among them
+    x = np.full(vocab, -25.0, dtype=np.float32)
+    x[heavy] = np.linspace(1.0, 3.0, 10).astype(np.float32)
+    dead = rng.choice(np.setdiff1d(np.arange(vocab), heavy), size=50, replace=False)
+    x[dead[:25]] = -np.inf
+    x[dead[25:]] = np.nan
+    logits = torch.from_numpy(np.tile(x, (B, 1))).to(device=device, dtype=dtype)
+    xr = logits[0].float().cpu().numpy().astype(np.float64)
+    ok = np.isfinite(xr)
+    want = np.zeros(vocab)
+    want[ok] = np.exp(xr[ok] / T - (xr[ok] / T).max())
+    want /= want.sum()
+    temp = torch.full((B,), T, device=device)
+    draws = torch.stack([ops.sample_topk_topp(logits, temp, None, None, seed=99, offset=c * B) for c in range(calls)])
+    draws = draws.cpu().numpy().ravel()
+    assert ok[draws].all()
+    n = draws.size
+    for t in heavy:
+        expect, got = want[t] * n, int((draws == t).sum())
+        assert abs(got - expect) <= 5.0 * np.sqrt(expect) + 3, f"token {t}: {got} draws, {expect:.0f} expected"
+    assert (np.isin(draws, heavy)).mean() > 0.999
+    # a row with nothing finite has nothing to draw from: token 0, and no fault
+    empty = torch.full((2, vocab), float('-inf'), device=device, dtype=dtype)
+    assert ops.sample_topk_topp(empty, torch.ones(2, device=device), None, None, seed=1).cpu().tolist() == [0, 0]
+
+
 def test_sampling_temperature_spread(ops, device):
     """Mirror of the reference's test_temperature_affects_distribution
     (05_mini_vllm/test_mini_vllm.py:195-211) on the kernel itself."""

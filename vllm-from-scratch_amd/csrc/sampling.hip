@@ -348,6 +348,7 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
   constexpr int NR = VPT > 0 ? VPT : 1;
   float pr[NR];
   float mx = -__builtin_inff(), z = 0.f;
+  float thread_top = -__builtin_inff();   // streamed rows: the largest x / T among this thread's elements
   const float inv_t = 1.0f / temp;
   const bool unit_temp = temp == 1.0f;   // x / 1 is x, exactly
   auto by_temp = [&](float x) { return unit_temp ? x : div_shared(x, temp, inv_t); };
@@ -479,7 +480,108 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
     for (int j = 0; j < VPT; ++j) pr[j] = (eidx(j) < vocab) ? div_shared(pr[j], z, inv_z) : -1.0f;   // -1 marks "no element"
   } else {
     draw_uniform();
+    // A streamed row without a cut whose distribution nobody asked for: ONE trip through memory.
+    // Every thread keeps a running maximum and the sum of its weights exp2((x/T - maximum) log2 e)
+    // relative to it (rescaled when a group of loads raises the maximum: one extra exponential per
+    // group, not per element); the threads' sums, brought to the row's maximum, are scanned for the
+    // thread the target falls to, and wave 0 alone re-reads that thread's hundred-odd elements to
+    // find the token.  (The general path below reads the row four times: maximum, sum, kept mass,
+    // and the picking thread's walk -- the last one by a single thread.)
+    if (!(tp < 1.0f || tk > 0) && !p.out_probs) {
+      constexpr float kL2e = 1.44269504088896340736f;
+      constexpr int GE = VEC ? EPL : 1;                  // elements per load
+      constexpr int kU = VEC ? 32 / EPL : 8;             // loads in flight per thread: 32 elements (8) per group
+      const int nload = VEC ? vocab / EPL : vocab;       // loads in the row
+      float m_t = -__builtin_inff(), z_t = 0.f;
+      for (int c0 = tid; c0 < nload; c0 += nt * kU) {
+        float xg[kU * GE];
+        if constexpr (VEC) {
+          u32x4 raw[kU];
+#pragma unroll
+          for (int u = 0; u < kU; ++u)
+            raw[u] = __builtin_nontemporal_load(
+                reinterpret_cast<const u32x4*>(row + (int64_t)min(c0 + u * nt, nload - 1) * EPL));
+#pragma unroll
+          for (int u = 0; u < kU; ++u) {
+            float f[EPL];
+            Tag::unpack(raw[u], f);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) xg[u * GE + e] = c0 + u * nt < nload ? by_temp(f[e]) : -__builtin_inff();
+          }
+        } else {
+          float x[kU];
+#pragma unroll
+          for (int u = 0; u < kU; ++u) x[u] = Tag::to_float(row[min(c0 + u * nt, nload - 1)]);
+#pragma unroll
+          for (int u = 0; u < kU; ++u) xg[u] = c0 + u * nt < nload ? by_temp(x[u]) : -__builtin_inff();
+        }
+        float gmax = xg[0];
+#pragma unroll
+        for (int i = 1; i < kU * GE; ++i) gmax = fmaxf(gmax, xg[i]);   // (a NaN logit never wins)
+        if (gmax > m_t) {
+          z_t *= __builtin_amdgcn_exp2f((m_t - gmax) * kL2e);                // first group: 0 * 0
+          m_t = gmax;
+        }
+        const float ref = m_t > -__builtin_inff() ? m_t : 0.f;               // (nothing finite yet: every weight 0)
+#pragma unroll
+        for (int i = 0; i < kU * GE; ++i)
+          z_t += fmaxf(__builtin_amdgcn_exp2f((xg[i] - ref) * kL2e), 0.f);   // NaN logit: weight 0
+      }
+      mx = block_reduce(m_t, fmaxop, xch, slot);
+      const float row_ref = mx > -__builtin_inff() ? mx : 0.f;
+      const float mine = m_t > -__builtin_inff() ? z_t * __builtin_amdgcn_exp2f((m_t - row_ref) * kL2e) : 0.f;
+      const float incl = wave_prefix_sum(mine);
+      if (lane == 63) s_scan[wave] = incl;
+      if (tid == 0) s_pick = 0x7fffffff;
+      __syncthreads();
+      float base = 0.f, total = 0.f;
+#pragma unroll
+      for (int w = 0; w < kMaxWaves; ++w) {
+        const float v = w < (nt >> 6) ? s_scan[w] : 0.f;
+        total += v;
+        base += w < wave ? v : 0.f;
+      }
+      const float target = s_uniform * total;
+      const float excl = base + incl - mine;
+      if (mine > 0.f && excl <= target && target < excl + mine) atomicMin(&s_pick, tid);
+      __syncthreads();
+      int picker = s_pick;
+      if (picker == 0x7fffffff) {      // rounding pushed the target past the total: the last thread with any weight
+        picker = block_reduce(mine > 0.f ? tid : -1, maxi, xch, slot);
+        if (picker < 0) {              // no finite logit in the row
+          if (tid == 0) p.out[b] = 0;
+          return;
+        }
+      }
+      if (tid == picker) s_walk_base = excl;
+      __syncthreads();
+      if (wave != 0) return;
+      // the picker's elements, in its own order, 64 at a time
+      const float tgt = target - s_walk_base;
+      const int owned = picker < nload ? ((nload - 1 - picker) / nt + 1) * GE : 0;
+      float carry = 0.f;
+      int last_weighted = -1;
+      for (int j0 = 0; j0 < owned; j0 += kWave) {
+        const int j = j0 + lane;
+        const int idx = ((j / GE) * nt + picker) * GE + (j % GE);
+        const float x = j < owned ? by_temp(Tag::to_float(row[j < owned ? idx : 0])) : -__builtin_inff();
+        const float w = fmaxf(__builtin_amdgcn_exp2f((x - row_ref) * kL2e), 0.f);
+        const float run = wave_prefix_sum(w) + carry;
+        const unsigned long long weighted = __ballot(w > 0.f);
+        const unsigned long long hit = __ballot(w > 0.f && run > tgt);
+        if (hit) {
+          const int l = __ffsll((long long)hit) - 1;
+          if (lane == l) p.out[b] = idx;
+          return;
+        }
+        if (weighted) last_weighted = __builtin_amdgcn_readlane(idx, 63 - __clzll((long long)weighted));
+        carry = lane_f(run, 63);
+      }
+      if (lane == 0) p.out[b] = max(last_weighted, 0);   // rounding again: the picker's last weighted element
+      return;
+    }
     stream_row([&](float x, int) { mx = fmaxf(mx, by_temp(x)); });
+    thread_top = mx;
     mx = block_reduce(mx, fmaxop, xch, slot);
     stream_row([&](float x, int) { z += exp_nonpos(by_temp(x) - mx); });
     z = block_reduce(z, addf, xch, slot);
@@ -487,13 +589,21 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
   const float inv_z_row = 1.0f / z;
   auto prob_of = [&](float x) { return div_shared(exp_nonpos(by_temp(x) - mx), z, inv_z_row); };
   // Visits every element this thread owns: fn(probability, index).
+  // Streamed rows under a top-k limit: once a lower bound of the k-th largest value is known (below),
+  // elements whose x / T lies under x_floor are passed over without computing their probability --
+  // two divisions and an exponential each, which is what a pass over such a row spends its time on.
+  bool floor_on = false;
+  float x_floor = 0.f;
   auto for_each = [&](auto fn) {
     if constexpr (VPT > 0) {
 #pragma unroll
       for (int j = 0; j < VPT; ++j)
         if (pr[j] >= 0.f) fn(pr[j], eidx(j));
     } else {
-      stream_row([&](float x, int i) { fn(prob_of(x), i); });
+      stream_row([&](float x, int i) {
+        const float xs = by_temp(x);
+        if (!floor_on || xs > x_floor) fn(div_shared(exp_nonpos(xs - mx), z, inv_z_row), i);
+      });
     }
   };
 
@@ -569,6 +679,24 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
         }
         if (lane == 0) s_wbound[wave] = kth;             // (read behind the first level's first barrier)
       }
+    } else {
+      // Streamed row: the same bound from the threads' largest x / T (kept from the first pass).
+      // Its probability, lowered by a few units in the last place, is the floor of the tallies --
+      // the computed probability need not be monotone in x / T to the last bit -- and elements more
+      // than 0.01 below it in x / T (a probability ratio of 0.99) are not even evaluated.
+      const int nw = nt >> 6;
+      const int per_wave = tk > 0 ? (tk + nw - 1) / nw : 0;
+      bounded = per_wave >= 1 && per_wave <= 8;
+      if (bounded) {
+        float top = thread_top;
+        float kth = -__builtin_inff();
+        for (int r = 0; r < per_wave; ++r) {
+          kth = wave_reduce(top, fmaxop);
+          const unsigned long long holders = __ballot(top == kth);
+          if (holders && lane == __ffsll((long long)holders) - 1) top = -__builtin_inff();
+        }
+        if (lane == 0) s_wbound[wave] = kth;
+      }
     }
     auto tally = [&](float q, int shift, int nbins) {
       atomicAdd(&s_hist[(__builtin_bit_cast(uint32_t, q) >> shift) & (uint32_t)(nbins - 1)],
@@ -635,7 +763,13 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
         float lowest = s_wbound[0];
 #pragma unroll
         for (int w = 1; w < kMaxWaves; ++w) lowest = fminf(lowest, s_wbound[w < (nt >> 6) ? w : 0]);
-        tally_from = fmaxf(lowest, 0.f);                 // (a wave without k' values reports -1: no bound)
+        if constexpr (VPT > 0) {
+          tally_from = fmaxf(lowest, 0.f);               // (a wave without k' values reports -1: no bound)
+        } else if (lowest > -__builtin_inff()) {         // (a wave without k' finite values: no bound)
+          tally_from = div_shared(exp_nonpos(lowest - mx), z, inv_z_row) * (1.0f - 0x1p-20f);
+          x_floor = lowest - 0.01f;
+          floor_on = true;
+        }
       }
       if (L > 0 && listed >= 0) {
         for (int i = tid; i < listed; i += nt) {
@@ -796,7 +930,10 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
 #ifndef SAMPLER_TIMING
   if (p.out_probs) {
     float* dst = p.out_probs + (int64_t)b * vocab;
+    const bool floored = floor_on;
+    floor_on = false;                                     // every element gets its entry
     for_each([&](float q, int i) { dst[i] = is_kept(q, i) ? q / kept_mass : 0.f; });
+    floor_on = floored;
   }
 #endif
 
@@ -863,18 +1000,34 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
     STAMP(23);
     if (wave == 0) walk_pick(picker, target);
   } else {
-    if (tid == picker) {
-      float run = excl;
-      int choice = -1, fallback = -1;
-      for_each([&](float q, int i) {
-        if (is_kept(q, i)) {
-          fallback = i;
-          run += q;
-          if (choice < 0 && run > target) choice = i;
-        }
-      });
-      p.out[b] = choice >= 0 ? choice : fallback;
+    // Streamed row: wave 0 re-reads the picking thread's elements, 64 at a time in that thread's
+    // order, and finds the first kept one whose running sum passes the target (one thread walking
+    // its hundred-odd elements alone, two divisions and an exponential each, took as long as a
+    // whole pass of the workgroup over the row).
+    if (tid == picker) s_walk_base = excl;
+    __syncthreads();
+    if (wave != 0) return;
+    constexpr int GE = VEC ? EPL : 1;
+    const int nload = VEC ? vocab / EPL : vocab;
+    const int owned = picker < nload ? ((nload - 1 - picker) / nt + 1) * GE : 0;
+    float carry = s_walk_base;
+    int last_kept = -1;
+    for (int j0 = 0; j0 < owned; j0 += kWave) {
+      const int j = j0 + lane;
+      const int idx = ((j / GE) * nt + picker) * GE + (j % GE);
+      const float q = j < owned ? prob_of(Tag::to_float(row[j < owned ? idx : 0])) : 0.f;
+      const bool kept = j < owned && is_kept(q, idx);
+      const float run = wave_prefix_sum(kept ? q : 0.f) + carry;
+      const unsigned long long kept_lanes = __ballot(kept);
+      const unsigned long long hit = __ballot(kept && run > target);
+      if (hit) {
+        if (lane == __ffsll((long long)hit) - 1) p.out[b] = idx;
+        return;
+      }
+      if (kept_lanes) last_kept = __builtin_amdgcn_readlane(idx, 63 - __clzll((long long)kept_lanes));
+      carry = lane_f(run, 63);
     }
+    if (lane == 0) p.out[b] = max(last_kept, 0);
   }
 }
 
