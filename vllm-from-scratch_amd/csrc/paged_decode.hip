@@ -44,6 +44,22 @@ constexpr int kLeadBytes = 64;   // the decode kernel's leading scalar arguments
 #define MI355_DECODE_WARM 1
 #endif
 
+// MI355_DECODE_TIMING (side builds only): thread 0 of every workgroup of a launch without token
+// splits writes the constant 100 MHz clock and the shader clock at five points of the kernel into
+// the caller's workspace (16 64-bit words per workgroup): tools/probe_decode_timeline.py.
+#ifdef MI355_DECODE_TIMING
+#define DECODE_STAMP(n)                                                                             \
+  do {                                                                                              \
+    if (threadIdx.x == 0 && p.nsplit == 1 && p.ws_acc) {                                            \
+      unsigned long long* st_ = reinterpret_cast<unsigned long long*>(p.ws_acc) + (size_t)blockIdx.x * 16; \
+      st_[2 * (n)] = __builtin_amdgcn_s_memrealtime();                                              \
+      st_[2 * (n) + 1] = __builtin_readcyclecounter();                                              \
+    }                                                                                               \
+  } while (0)
+#else
+#define DECODE_STAMP(n) do { } while (0)
+#endif
+
 template <class Tag, int D>
 struct Geo {
   static constexpr int EPL = Tag::kEPL;      // elements per 16-byte lane load
@@ -89,6 +105,7 @@ paged_decode_kernel(const int32_t* a_bt, const int32_t* a_ctx, const void* a_q, 
 #else
   int bid = blockIdx.x;
 #endif
+  DECODE_STAMP(0);
   const int qc = bid % a_qchunks;
   bid /= a_qchunks;
   const int hg = bid % a_hgroups;
@@ -212,6 +229,7 @@ paged_decode_kernel(const int32_t* a_bt, const int32_t* a_ctx, const void* a_q, 
   // never use from standing in the way of the stream's own loads: a register whose load might
   // still be pending cannot be reused without waiting for everything issued after it.
   if constexpr (APPEND) asm("" : "+v"(new_k), "+v"(new_v));
+  DECODE_STAMP(1);
   // ROWS: the group's own context is shared out between the sub-range waves (early groups are short)
   const int len_w = ROWS ? (ctx + p.sub * TS - 1) / (p.sub * TS) * TS : p.tps / p.sub;
   const int tw0 = t0 + sb * len_w;
@@ -342,10 +360,14 @@ paged_decode_kernel(const int32_t* a_bt, const int32_t* a_ctx, const void* a_q, 
     for (int s = 0; s < nsteps; s += 2) {
       if (s + 1 < nsteps) load_step(s + 1, kb, vb);
       compute_step(s, ka, va);
+#ifdef MI355_DECODE_TIMING
+      if (s == 0) DECODE_STAMP(2);
+#endif
       if (s + 2 < nsteps) load_step(s + 2, ka, va);
       if (s + 1 < nsteps) compute_step(s + 1, kb, vb);
     }
   }
+  DECODE_STAMP(3);
 
   // Merge the TPL lane groups of the wave (same dims, different tokens).
   auto fmax_op = [](float a, float c) { return fmaxf(a, c); };
@@ -406,6 +428,7 @@ paged_decode_kernel(const int32_t* a_bt, const int32_t* a_ctx, const void* a_q, 
     }
   }
 
+  DECODE_STAMP(4);
   const bool owner = sb == 0 && lane < LPT;
   if (!owner && !fused) return;
 #pragma unroll
