@@ -374,6 +374,8 @@ def main():
         # HBM bytes per launch from the committed counter passes (tools/collect_profiles.sh +
         # tools/pmc_traffic.py; counters cannot be read inside this process)
         traffic, note = measured_traffic(args.config, lib_hash)
+        if args.fused_step and traffic is not None:   # the counters were collected on the two-launch step's kernel
+            traffic, note = None, {"traffic_stale": "counters were collected for mi355_paged_decode, not for the append kernel"}
         line["roofline"]["traffic"] = traffic
         line["roofline"].update(note)
         # the same achieved figure against what this box's HBM gives plain streaming kernels
