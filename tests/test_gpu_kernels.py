@@ -1049,6 +1049,43 @@ def test_sampling_distribution(ops, device):
     assert not np.array_equal(ids, other)
 
 
+@pytest.mark.parametrize('vocab', [5000, 20000, 32000])
+def test_sampling_nucleus_from_flat_to_peaked_rows(ops, device, vocab):
+    """Kept sets against the oracle for nucleus cuts from 0.3 to 0.999 on rows from flat to very
+    peaked (a few tokens carry most of the mass, as a model's logits do), alone and under a top-k
+    limit, and on a row whose mass sits in one token."""
+    rng = np.random.default_rng(vocab + 3)
+    rows, temps, top_ps, top_ks = [], [], [], []
+    for std in (1.0, 2.5, 4.0, 7.0):
+        x = (rng.standard_normal(vocab) * std).astype(np.float32)
+        for p in (0.3, 0.9, 0.99, 0.999):
+            rows.append(x); temps.append(1.0); top_ps.append(p); top_ks.append(0)
+        rows.append(x); temps.append(0.7); top_ps.append(0.95); top_ks.append(40)
+    onehot = np.full(vocab, -20.0, dtype=np.float32)
+    onehot[vocab // 3] = 5.0                                         # one token holds everything
+    rows.append(onehot); temps.append(1.0); top_ps.append(0.9); top_ks.append(0)
+    logits = np.stack(rows)
+    ids, probs = ops.sample_topk_topp(torch.from_numpy(logits).to(device), torch.tensor(temps, device=device),
+                                      torch.tensor(top_ps, device=device),
+                                      torch.tensor(top_ks, dtype=torch.int32, device=device), seed=21, return_probs=True)
+    probs = probs.cpu().numpy()
+    for b in range(len(rows)):
+        want, kept = orc.nucleus_probs(logits[b], temps[b], top_ps[b], top_ks[b])
+        got_kept = probs[b] > 0
+        diff = np.nonzero(got_kept != kept)[0]
+        # Where the cut runs through the far tail (top_p 0.99 and beyond: thousands of tokens of 1e-8
+        # each) the oracle's float32 running sum over thousands of terms near 1 is only good to a few
+        # 1e-6, i.e. dozens of such tokens: the sets may differ by tokens that together carry less than
+        # a hundred-thousandth; elsewhere by one token.
+        full = np.exp(logits[b].astype(np.float64) / temps[b] - (logits[b].astype(np.float64) / temps[b]).max())
+        full /= full.sum()
+        assert len(diff) <= 1 or full[diff].sum() < 1e-5, \
+            f"row {b} (top_p {top_ps[b]}): kept sets differ at {diff[:8]} ({got_kept.sum()} vs {kept.sum()})"
+        if len(diff) == 0:
+            np.testing.assert_allclose(probs[b], want, rtol=2e-4, atol=1e-9)
+        assert got_kept[int(ids[b])]
+
+
 @pytest.mark.parametrize('dtype,vocab', [(torch.float32, 40000), (torch.float32, 70001), (torch.bfloat16, 131072)])
 def test_sampling_streamed_rows_without_a_cut_follow_the_softmax(ops, device, dtype, vocab):
     """Rows longer than the registers hold, no cut, no distribution asked for (one trip through

@@ -1,5 +1,5 @@
 """Sampler kernel timings by mode (HIP events around each call; run under rocprofv3 for kernel times).
-Usage: python tools/bench_sampler.py [batch vocab]"""
+Usage: python tools/bench_sampler.py [batch vocab [logit_std]]   (logit_std 1: flat rows; 4-6: peaked rows, as a model's)"""
 import os
 import sys
 
@@ -7,10 +7,11 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 import torch
 from mi355_paged import ops
 
-B, V = ([int(x) for x in sys.argv[1:]] + [256, 32000])[:2]
+B, V = ([int(x) for x in sys.argv[1:3]] + [256, 32000])[:2]
+STD = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
 dev = torch.device('cuda', 0)
 g = torch.Generator(device=dev).manual_seed(1)
-logits = [torch.randn((B, V), generator=g, device=dev) for _ in range(4)]
+logits = [torch.randn((B, V), generator=g, device=dev) * STD for _ in range(4)]
 temp = torch.full((B,), 0.8, device=dev)
 modes = {
     'argmax': lambda x: ops.sample_argmax(x),
@@ -35,4 +36,4 @@ for name, fn in modes.items():
         fn(logits[i % 4])
     b.record()
     torch.cuda.synchronize()
-    print(f"B={B} vocab={V} {name}: {a.elapsed_time(b) / n * 1e3:.1f} us per call", flush=True)
+    print(f"B={B} vocab={V}{'' if STD == 1.0 else f' std={STD:g}'} {name}: {a.elapsed_time(b) / n * 1e3:.1f} us per call", flush=True)
