@@ -351,7 +351,9 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
   float thread_top = -__builtin_inff();   // streamed rows: the largest x / T among this thread's elements
   const float inv_t = 1.0f / temp;
   const bool unit_temp = temp == 1.0f;   // x / 1 is x, exactly
-  auto by_temp = [&](float x) { return unit_temp ? x : div_shared(x, temp, inv_t); };
+  // a row without a cut whose distribution nobody asked for only needs its draw (the short paths below)
+  const bool draw_only = !(tp < 1.0f || tk > 0) && !p.out_probs;
+  auto by_temp = [&](float x) { return unit_temp ? x : draw_only ? x * inv_t : div_shared(x, temp, inv_t); };
   // Rows that do not fit the registers are streamed from memory on every pass: fn(logit, index)
   // for the thread's elements tid, tid + nt, ... in that order, kStreamU loads in flight per thread
   // (the index is clamped instead of branching around the load, so that the loads of a group
@@ -413,8 +415,13 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
       draw_uniform();
     }
     if (!unit_temp) {   // (wave-uniform: a row at temperature 1 skips 32 divisions per thread)
+      if (draw_only) {  // no cut to pin: the product with 1 / T is within an ulp of the quotient
 #pragma unroll
-      for (int j = 0; j < VPT; ++j) pr[j] = div_shared(pr[j], temp, inv_t);
+        for (int j = 0; j < VPT; ++j) pr[j] *= inv_t;
+      } else {
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) pr[j] = div_shared(pr[j], temp, inv_t);
+      }
     }
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
@@ -427,7 +434,7 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
     // e = exp2((x/T - max) log2 e) (a plain exp2: the extra digits of exp_nonpos pin the kept set of
     // a cut, here they would only move a draw by an ulp of the target), no division by their sum --
     // the target is scaled instead -- and the sum itself falls out of the scan over threads.
-    if (!(tp < 1.0f || tk > 0) && !p.out_probs) {
+    if (draw_only) {
       float mine = 0.f;
 #pragma unroll
       for (int j = 0; j < VPT; ++j) {
@@ -487,7 +494,7 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
     // thread the target falls to, and wave 0 alone re-reads that thread's hundred-odd elements to
     // find the token.  (The general path below reads the row four times: maximum, sum, kept mass,
     // and the picking thread's walk -- the last one by a single thread.)
-    if (!(tp < 1.0f || tk > 0) && !p.out_probs) {
+    if (draw_only) {
       constexpr float kL2e = 1.44269504088896340736f;
       constexpr int GE = VEC ? EPL : 1;                  // elements per load
       constexpr int kU = VEC ? 32 / EPL : 8;             // loads in flight per thread: 32 elements (8) per group
