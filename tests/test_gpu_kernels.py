@@ -1049,6 +1049,33 @@ def test_sampling_distribution(ops, device):
     assert not np.array_equal(ids, other)
 
 
+def test_sampling_top_k_on_streamed_rows_at_extreme_temperatures(ops, device):
+    """Rows beyond the registers under a top-k limit (elements far below a bound of the k-th largest
+    x / T are skipped unevaluated), at temperatures that make x / T small, ordinary and so large that
+    neighbouring floats are further apart than the bound's margin: exactly the k largest stay."""
+    rng = np.random.default_rng(12)
+    vocab = 50000
+    x = (rng.standard_normal(vocab) * 3).astype(np.float32)
+    rows, temps, top_ks = [], [], []
+    for t in (50.0, 1.0, 0.02, 1e-5):
+        for k in (1, 7, 50, 128):
+            rows.append(x); temps.append(t); top_ks.append(k)
+    logits = np.stack(rows)
+    ids, probs = ops.sample_topk_topp(torch.from_numpy(logits).to(device), torch.tensor(temps, device=device), None,
+                                      torch.tensor(top_ks, dtype=torch.int32, device=device), seed=4, return_probs=True)
+    probs = probs.cpu().numpy()
+    order = np.argsort(-x, kind='stable')
+    for b in range(len(rows)):
+        got = set(np.nonzero(probs[b] > 0)[0].tolist())
+        # at the coldest temperatures tokens underflow to probability 0 and carry nothing: of the k
+        # largest, those clearly above the smallest float must be there, those clearly below it not
+        weight = {int(i): np.exp((np.float64(x[i]) - np.float64(x[order[0]])) / temps[b]) for i in order[:top_ks[b]]}
+        must = {i for i, w in weight.items() if w > 1e-36}
+        may = {i for i, w in weight.items() if w > 1e-46}
+        assert must <= got <= may, f"row {b} (T={temps[b]}, k={top_ks[b]}): {len(got)} kept, {len(must)}..{len(may)} expected"
+        assert abs(probs[b].sum() - 1.0) < 1e-4 and int(ids[b]) in got
+
+
 @pytest.mark.parametrize('vocab', [5000, 20000, 32000])
 def test_sampling_nucleus_from_flat_to_peaked_rows(ops, device, vocab):
     """Kept sets against the oracle for nucleus cuts from 0.3 to 0.999 on rows from flat to very

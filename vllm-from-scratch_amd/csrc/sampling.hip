@@ -609,7 +609,7 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
     } else {
       stream_row([&](float x, int i) {
         const float xs = by_temp(x);
-        if (!floor_on || xs > x_floor) fn(div_shared(exp_nonpos(xs - mx), z, inv_z_row), i);
+        if (!floor_on || xs >= x_floor) fn(div_shared(exp_nonpos(xs - mx), z, inv_z_row), i);
       });
     }
   };
@@ -774,8 +774,8 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
           tally_from = fmaxf(lowest, 0.f);               // (a wave without k' values reports -1: no bound)
         } else if (lowest > -__builtin_inff()) {         // (a wave without k' finite values: no bound)
           tally_from = div_shared(exp_nonpos(lowest - mx), z, inv_z_row) * (1.0f - 0x1p-20f);
-          x_floor = lowest - 0.01f;
-          floor_on = true;
+          x_floor = lowest - 0.01f;                      // (where 0.01 is below the spacing of floats at `lowest`,
+          floor_on = true;                               //  this is `lowest` itself: the test is >=)
         }
       }
       if (L > 0 && listed >= 0) {
