@@ -130,3 +130,54 @@ def test_append_bad_arguments(ops, device):
         ops.paged_decode_append(pr['q'], pr['kn'][:, :4], pr['vn'][:, :4], c[0], c[1], pr['bt'], pr['ctx'], 64)
     with pytest.raises(TypeError):
         ops.paged_decode_append(pr['q'], pr['kn'].float(), pr['vn'].float(), c[0], c[1], pr['bt'], pr['ctx'], 64)
+
+
+def test_append_random_shapes(ops, device):
+    """Forty shapes drawn at random (batch, head grouping, head_dim, block size 1-64, ragged contexts
+    with empty rows, three dtypes, both layouts): the fused call against the two it replaces."""
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        Hkv = int(rng.choice([1, 2, 4, 8]))
+        gq = int(rng.choice([1, 1, 2, 4, 8]))
+        D = int(rng.choice([16, 32, 64, 128, 256]))
+        BS = int(rng.choice([1, 2, 4, 8, 16, 16, 32, 64]))
+        B = int(rng.integers(1, 40))
+        max_ctx = int(rng.integers(1, 700))
+        dtype = [torch.float32, torch.bfloat16, torch.float16][int(rng.integers(0, 3))]
+        layout = ['NHSD', 'NSHD'][int(rng.integers(0, 2))]
+        ctx = rng.integers(0, max_ctx + 1, size=B)
+        ctx[int(rng.integers(0, B))] = max_ctx
+        pr = _problem(rng, device, dtype, B, Hkv * gq, Hkv, D, BS, max_ctx, layout, ctx=ctx)
+        want, got, two, one = _both_ways(ops, pr)
+        assert torch.equal(want.view(torch.uint8), got.view(torch.uint8)), (case, B, Hkv, gq, D, BS, max_ctx, dtype, layout)
+        assert torch.equal(two.view(torch.uint8), one.view(torch.uint8)), (case, B, Hkv, gq, D, BS, max_ctx, dtype, layout)
+        assert not torch.isnan(got.float()).any()
+
+
+def test_append_replays_in_a_graph(ops, device):
+    """The fused call captured in a HIP graph and replayed on new inputs (same addresses): every
+    replay writes the row it is given and attends over it."""
+    rng = np.random.default_rng(31)
+    for B, ctx_len in ((16, 300), (2, 9000)):          # without and with token splits merged in the launch
+        pr = _problem(rng, device, torch.bfloat16, B, 8, 8, 64, 16, ctx_len, 'NHSD', ctx=np.full(B, ctx_len))
+        cache = pr['cache'].clone()
+        out = torch.empty_like(pr['q'])
+        ops.paged_decode_append(pr['q'], pr['kn'], pr['vn'], cache[0], cache[1], pr['bt'], pr['ctx'], pr['max_ctx'], out=out)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            ops.paged_decode_append(pr['q'], pr['kn'], pr['vn'], cache[0], cache[1], pr['bt'], pr['ctx'], pr['max_ctx'], out=out)
+        for _ in range(3):
+            pr['kn'].copy_(torch.randn_like(pr['kn']))
+            pr['vn'].copy_(torch.randn_like(pr['vn']))
+            pr['q'].copy_(torch.randn_like(pr['q']))
+            _poison(pr, cache)
+            g.replay()
+            torch.cuda.synchronize()
+            ref = cache.clone()
+            _poison(pr, ref)
+            ops.kv_write_slots(ref[0], ref[1], pr['kn'], pr['vn'], pr['slots'])
+            want = ops.paged_decode(pr['q'], ref[0], ref[1], pr['bt'], pr['ctx'], pr['max_ctx'])
+            torch.cuda.synchronize()
+            assert torch.equal(want.view(torch.uint8), out.view(torch.uint8))
+            assert torch.equal(ref.view(torch.uint8), cache.view(torch.uint8))
