@@ -66,6 +66,11 @@ __device__ __forceinline__ float wave_prefix_sum(float v) {
   v += dpp_move_f<0x143, 0xc>(v);
   return v;
 }
+__device__ __forceinline__ unsigned long long lane_u64(unsigned long long v, int l) {   // l wave-uniform
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+  return ((unsigned long long)hi << 32) | lo;
+}
 __device__ __forceinline__ unsigned long long wave_prefix_sum_u64(unsigned long long v) {
   v += dpp_move_u64<0x111, 0xf>(v);   // row_shr:1
   v += dpp_move_u64<0x112, 0xf>(v);   // row_shr:2
@@ -811,12 +816,12 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
         if (lane == kWave - 1) s_wsum[wave] = incl;
         if (tid == 0) s_cutbin = -1;
         __syncthreads();
+        // what the waves before this one hold: one entry per lane, a prefix sum over the first row of
+        // lanes, the entry of wave - 1 broadcast (sixteen reads and selected additions per thread before)
+        const unsigned long long mine_w = lane < (nt >> 6) ? s_wsum[lane < kMaxWaves ? lane : 0] : 0ull;
+        const unsigned long long upto = wave_prefix_sum_u64(mine_w);
         unsigned long long run = acc + (incl - own);
-#pragma unroll
-        for (int w = 0; w < kMaxWaves; ++w) {              // (all reads issue together)
-          const unsigned long long v = s_wsum[w < (nt >> 6) ? w : 0];
-          run += w < wave ? v : 0ull;
-        }
+        if (wave > 0) run += lane_u64(upto, wave - 1);
         if (has) {
           bool pass_here = ok(mass_of(run), (int)(run >> 41));
           for (int i = 0; i < bpt; ++i) {
