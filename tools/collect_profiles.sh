@@ -79,5 +79,7 @@ step secondary benchmarks
   timeout -k 10 200 python3 bench.py --no-cpu-baseline
   timeout -k 10 200 python3 bench.py --no-cpu-baseline --config c2 --fused-step
   timeout -k 10 200 python3 bench.py --no-cpu-baseline --config c2
+  echo "fixed total batch (--strong 2048) on one GPU: 2048 sequences in one launch"
+  timeout -k 10 200 python3 bench.py --no-cpu-baseline --strong 2048
 } > "$OUT/secondary.txt" 2> "$OUT/secondary.err"
 find "$OUT" -name '*.csv' | head -40 >&2
