@@ -1076,6 +1076,57 @@ def test_sampling_top_k_on_streamed_rows_at_extreme_temperatures(ops, device):
         assert abs(probs[b].sum() - 1.0) < 1e-4 and int(ids[b]) in got
 
 
+def test_sampling_top_k_on_streamed_rows_from_the_candidate_list(ops, device):
+    """Rows beyond the registers under a top-k limit keep the elements at or above the bound in a
+    list of at most one per thread: rows whose candidates fit (distinct values; 600 copies of the
+    largest value) and rows where they cannot (3000 copies; a constant row) keep the same set -- of
+    equal values the lowest indices -- and the draws follow the kept distribution."""
+    rng = np.random.default_rng(77)
+    vocab = 70001
+    base = (rng.standard_normal(vocab) * 2).astype(np.float32)
+    rows = [base.copy()]
+    for copies in (600, 3000):
+        x = base.copy()
+        x[rng.choice(vocab, size=copies, replace=False)] = 9.0
+        rows.append(x)
+    rows.append(np.full(vocab, 0.25, dtype=np.float32))
+    k = 50
+    logits = torch.from_numpy(np.stack(rows)).to(device)
+    temps = torch.ones(len(rows), device=device)
+    top_ks = torch.full((len(rows),), k, dtype=torch.int32, device=device)
+    ids, probs = ops.sample_topk_topp(logits, temps, None, top_ks, seed=9, return_probs=True)
+    probs = probs.cpu().numpy()
+    kept_sets = []
+    for b, x in enumerate(rows):
+        want = np.sort(np.argsort(-x, kind='stable')[:k])
+        got = np.nonzero(probs[b] > 0)[0]
+        assert np.array_equal(got, want), f"row {b}: {len(got)} kept"
+        ref = np.exp(x[want].astype(np.float64) - x[want].max())
+        np.testing.assert_allclose(probs[b][want], ref / ref.sum(), rtol=2e-5, atol=1e-7)
+        assert int(ids[b]) in set(want.tolist())
+        kept_sets.append(want)
+    # the same seed gives the same tokens, call after call (the list's order of arrival must not show)
+    again = ops.sample_topk_topp(logits, temps, None, top_ks, seed=9)
+    assert torch.equal(ids, again)
+    # drawn frequencies over 60 seeds x 64 copies of each row against the kept distribution
+    reps = 64
+    tiled = logits.repeat_interleave(reps, dim=0)
+    t_temps = torch.ones(tiled.shape[0], device=device)
+    t_ks = torch.full((tiled.shape[0],), k, dtype=torch.int32, device=device)
+    counts = np.zeros((len(rows), vocab), dtype=np.int64)
+    nseeds = 60
+    for seed in range(nseeds):
+        got = ops.sample_topk_topp(tiled, t_temps, None, t_ks, seed=1000 + seed).cpu().numpy().reshape(len(rows), reps)
+        for b in range(len(rows)):
+            np.add.at(counts[b], got[b], 1)
+    n = nseeds * reps
+    for b in range(len(rows)):
+        assert counts[b].sum() == n and counts[b][kept_sets[b]].sum() == n
+        expect = probs[b][kept_sets[b]].astype(np.float64) * n
+        sigma = np.sqrt(np.maximum(expect * (1 - expect / n), 1.0))
+        assert np.all(np.abs(counts[b][kept_sets[b]] - expect) < 5.5 * sigma), f"row {b}"
+
+
 @pytest.mark.parametrize('vocab', [5000, 20000, 32000])
 def test_sampling_nucleus_from_flat_to_peaked_rows(ops, device, vocab):
     """Kept sets against the oracle for nucleus cuts from 0.3 to 0.999 on rows from flat to very

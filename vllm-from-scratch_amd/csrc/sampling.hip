@@ -312,6 +312,12 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
   constexpr int kListCap = 4096;
   __shared__ float s_list[kListCap];
   __shared__ int s_list_n;
+  // streamed rows under a top-k limit: the few elements at or above the bound (x / T and index), as
+  // they arrive and ordered by index
+  constexpr int kCandCap = VPT == 0 ? NT : 1;
+  __shared__ float s_cand_x[kCandCap], s_cand_sx[kCandCap];
+  __shared__ int s_cand_i[kCandCap], s_cand_si[kCandCap];
+  __shared__ int s_cand_n;
   constexpr int kTieCap = 64;
   __shared__ int s_tie_i[kTieCap];
   __shared__ int s_tie_n;
@@ -604,13 +610,20 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
   // Streamed rows under a top-k limit: once a lower bound of the k-th largest value is known (below),
   // elements whose x / T lies under x_floor are passed over without computing their probability --
   // two divisions and an exponential each, which is what a pass over such a row spends its time on.
-  bool floor_on = false;
+  // When no more of them than threads pass that test (the usual case: a few hundred of 128256), one
+  // trip through the row collects them in LDS, ordered by index so that the draw does not depend on
+  // the order of arrival, and every later visit is one element per thread from that list instead of
+  // another trip through memory.
+  bool floor_on = false, cand_on = false;
   float x_floor = 0.f;
+  int cand_n = 0;
   auto for_each = [&](auto fn) {
     if constexpr (VPT > 0) {
 #pragma unroll
       for (int j = 0; j < VPT; ++j)
         if (pr[j] >= 0.f) fn(pr[j], eidx(j));
+    } else if (cand_on) {
+      if (tid < cand_n) fn(div_shared(exp_nonpos(s_cand_sx[tid] - mx), z, inv_z_row), s_cand_si[tid]);
     } else {
       stream_row([&](float x, int i) {
         const float xs = by_temp(x);
@@ -764,6 +777,43 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
       prefix = s_cutbits;
       acc = s_above;
     };
+    if constexpr (VPT == 0) {
+      if (bounded) {
+        if (tid == 0) s_cand_n = 0;
+        __syncthreads();                                 // the waves' bounds are in
+        float lowest = s_wbound[0];
+#pragma unroll
+        for (int w = 1; w < kMaxWaves; ++w) lowest = fminf(lowest, s_wbound[w < (nt >> 6) ? w : 0]);
+        if (lowest > -__builtin_inff()) {                // (a wave without k' finite values: no bound)
+          tally_from = div_shared(exp_nonpos(lowest - mx), z, inv_z_row) * (1.0f - 0x1p-20f);
+          x_floor = lowest - 0.01f;                      // (where 0.01 is below the spacing of floats at `lowest`,
+          floor_on = true;                               //  this is `lowest` itself: the test is >=)
+          stream_row([&](float x, int i) {
+            const float xs = by_temp(x);
+            if (xs >= x_floor) {
+              const int at = atomicAdd(&s_cand_n, 1);
+              if (at < kCandCap) {
+                s_cand_x[at] = xs;
+                s_cand_i[at] = i;
+              }
+            }
+          });
+          __syncthreads();
+          cand_n = s_cand_n;
+          if (cand_n <= kCandCap) {                      // (else: the row is walked as before)
+            if (tid < cand_n) {
+              const int mine_i = s_cand_i[tid];
+              int rank = 0;
+              for (int m = 0; m < cand_n; ++m) rank += s_cand_i[m] < mine_i ? 1 : 0;
+              s_cand_sx[rank] = s_cand_x[tid];
+              s_cand_si[rank] = mine_i;
+            }
+            __syncthreads();
+            cand_on = true;
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int L = 0; L < 3; ++L) {
       if (L > 0 && listed >= 0 && listed <= kWaveFinishMax) continue;   // (finished below, by wave 0)
@@ -771,16 +821,12 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
       for (int i = tid; i < nbins; i += nt) s_hist[i] = 0ull;
       __syncthreads();
       STAMP(3 + 5 * L);
-      if (L == 0 && bounded) {
-        float lowest = s_wbound[0];
+      if constexpr (VPT > 0) {
+        if (L == 0 && bounded) {
+          float lowest = s_wbound[0];
 #pragma unroll
-        for (int w = 1; w < kMaxWaves; ++w) lowest = fminf(lowest, s_wbound[w < (nt >> 6) ? w : 0]);
-        if constexpr (VPT > 0) {
+          for (int w = 1; w < kMaxWaves; ++w) lowest = fminf(lowest, s_wbound[w < (nt >> 6) ? w : 0]);
           tally_from = fmaxf(lowest, 0.f);               // (a wave without k' values reports -1: no bound)
-        } else if (lowest > -__builtin_inff()) {         // (a wave without k' finite values: no bound)
-          tally_from = div_shared(exp_nonpos(lowest - mx), z, inv_z_row) * (1.0f - 0x1p-20f);
-          x_floor = lowest - 0.01f;                      // (where 0.01 is below the spacing of floats at `lowest`,
-          floor_on = true;                               //  this is `lowest` itself: the test is >=)
         }
       }
       if (L > 0 && listed >= 0) {
@@ -942,10 +988,11 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
 #ifndef SAMPLER_TIMING
   if (p.out_probs) {
     float* dst = p.out_probs + (int64_t)b * vocab;
-    const bool floored = floor_on;
-    floor_on = false;                                     // every element gets its entry
+    const bool floored = floor_on, from_list = cand_on;
+    floor_on = cand_on = false;                           // every element gets its entry
     for_each([&](float q, int i) { dst[i] = is_kept(q, i) ? q / kept_mass : 0.f; });
     floor_on = floored;
+    cand_on = from_list;
   }
 #endif
 
@@ -1016,6 +1063,10 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
     // order, and finds the first kept one whose running sum passes the target (one thread walking
     // its hundred-odd elements alone, two divisions and an exponential each, took as long as a
     // whole pass of the workgroup over the row).
+    if (cand_on) {                     // the picking thread's one element
+      if (tid == picker) p.out[b] = s_cand_si[tid];
+      return;
+    }
     if (tid == picker) s_walk_base = excl;
     __syncthreads();
     if (wave != 0) return;
