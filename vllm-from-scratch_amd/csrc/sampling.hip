@@ -3,6 +3,7 @@
 // One workgroup owns one row of logits.  Row maxima, argmax pairs, probability
 // sums and counts are reduced with wave shuffles first and a small LDS exchange
 // across the waves of the workgroup second.
+#include <type_traits>
 #include <math.h>
 
 #include "common.h"
@@ -505,20 +506,30 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
     // thread the target falls to, and wave 0 alone re-reads that thread's hundred-odd elements to
     // find the token.  (The general path below reads the row four times: maximum, sum, kept mass,
     // and the picking thread's walk -- the last one by a single thread.)
-    if (draw_only) {
-      constexpr float kL2e = 1.44269504088896340736f;
-      constexpr int GE = VEC ? EPL : 1;                  // elements per load
-      constexpr int kU = VEC ? 32 / EPL : 8;             // loads in flight per thread: 32 elements (8) per group
-      const int nload = VEC ? vocab / EPL : vocab;       // loads in the row
-      float m_t = -__builtin_inff(), z_t = 0.f;
+    constexpr float kL2e = 1.44269504088896340736f;
+    constexpr int GE = VEC ? EPL : 1;                  // elements per load
+    constexpr int kU = VEC ? 32 / EPL : 8;             // loads in flight per thread: 32 elements (8) per group
+    const int nload = VEC ? vocab / EPL : vocab;       // loads in the row
+    // One trip through the row: the thread's running maximum of x / T and the sum of its weights relative
+    // to it.  `once`: the row is not read again (loads that bypass the caches, weights by the bare
+    // exp2 instruction); otherwise the weights are formed as the probabilities will be.
+    auto online_max_sum = [&](auto once, float& m_t, float& z_t) {
+      constexpr bool kOnce = decltype(once)::value;
+      auto load_piece = [&](const u32x4* at) {
+        if constexpr (kOnce) return __builtin_nontemporal_load(at); else return *at;
+      };
+      auto weight = [&](float d) {
+        if constexpr (kOnce) return __builtin_amdgcn_exp2f(d * kL2e); else return exp_nonpos(d);
+      };
+      m_t = -__builtin_inff();
+      z_t = 0.f;
       for (int c0 = tid; c0 < nload; c0 += nt * kU) {
         float xg[kU * GE];
         if constexpr (VEC) {
           u32x4 raw[kU];
 #pragma unroll
           for (int u = 0; u < kU; ++u)
-            raw[u] = __builtin_nontemporal_load(
-                reinterpret_cast<const u32x4*>(row + (int64_t)min(c0 + u * nt, nload - 1) * EPL));
+            raw[u] = load_piece(reinterpret_cast<const u32x4*>(row + (int64_t)min(c0 + u * nt, nload - 1) * EPL));
 #pragma unroll
           for (int u = 0; u < kU; ++u) {
             float f[EPL];
@@ -537,14 +548,18 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
 #pragma unroll
         for (int i = 1; i < kU * GE; ++i) gmax = fmaxf(gmax, xg[i]);   // (a NaN logit never wins)
         if (gmax > m_t) {
-          z_t *= __builtin_amdgcn_exp2f((m_t - gmax) * kL2e);                // first group: 0 * 0
+          z_t *= weight(m_t - gmax);                                         // first group: 0 * 0
           m_t = gmax;
         }
         const float ref = m_t > -__builtin_inff() ? m_t : 0.f;               // (nothing finite yet: every weight 0)
 #pragma unroll
         for (int i = 0; i < kU * GE; ++i)
-          z_t += fmaxf(__builtin_amdgcn_exp2f((xg[i] - ref) * kL2e), 0.f);   // NaN logit: weight 0
+          z_t += fmaxf(weight(xg[i] - ref), 0.f);                            // NaN logit: weight 0
       }
+    };
+    if (draw_only) {
+      float m_t, z_t;
+      online_max_sum(std::true_type{}, m_t, z_t);
       mx = block_reduce(m_t, fmaxop, xch, slot);
       const float row_ref = mx > -__builtin_inff() ? mx : 0.f;
       const float mine = m_t > -__builtin_inff() ? z_t * __builtin_amdgcn_exp2f((m_t - row_ref) * kL2e) : 0.f;
@@ -598,11 +613,12 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
       if (lane == 0) p.out[b] = max(last_weighted, 0);   // rounding again: the picker's last weighted element
       return;
     }
-    stream_row([&](float x, int) { mx = fmaxf(mx, by_temp(x)); });
-    thread_top = mx;
-    mx = block_reduce(mx, fmaxop, xch, slot);
-    stream_row([&](float x, int) { z += exp_nonpos(by_temp(x) - mx); });
-    z = block_reduce(z, addf, xch, slot);
+    // with a cut: maximum and sum in one trip as well, the threads' sums brought to the row's maximum
+    float m_t, z_t;
+    online_max_sum(std::false_type{}, m_t, z_t);
+    thread_top = m_t;
+    mx = block_reduce(m_t, fmaxop, xch, slot);
+    z = block_reduce(m_t > -__builtin_inff() ? z_t * exp_nonpos(m_t - mx) : 0.f, addf, xch, slot);
   }
   const float inv_z_row = 1.0f / z;
   auto prob_of = [&](float x) { return div_shared(exp_nonpos(by_temp(x) - mx), z, inv_z_row); };
