@@ -504,8 +504,8 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
     // relative to it (rescaled when a group of loads raises the maximum: one extra exponential per
     // group, not per element); the threads' sums, brought to the row's maximum, are scanned for the
     // thread the target falls to, and wave 0 alone re-reads that thread's hundred-odd elements to
-    // find the token.  (The general path below reads the row four times: maximum, sum, kept mass,
-    // and the picking thread's walk -- the last one by a single thread.)
+    // find the token.  (A row with a cut shares the first trip -- online_max_sum below -- and then
+    // makes further ones for the cut search and the kept mass.)
     constexpr float kL2e = 1.44269504088896340736f;
     constexpr int GE = VEC ? EPL : 1;                  // elements per load
     constexpr int kU = VEC ? 32 / EPL : 8;             // loads in flight per thread: 32 elements (8) per group
