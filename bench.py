@@ -156,21 +156,31 @@ def library_sha256():
     return h.hexdigest()
 
 
-def measured_traffic(config_name, lib_hash):
-    """(bytes per launch or None, note) from the newest committed counter digest of this config
-    that was collected with the library now loaded."""
+def measured_traffic(config_name, lib_hash, batch):
+    """(bytes per launch or None, note) from the committed counter digest of this config that was
+    collected with the library now loaded, at the batch this run launches.  Every digest of the
+    config is a candidate (file dates mean nothing after a checkout); the one whose library hash
+    matches is taken, the highest name first among several."""
     import glob
     suffix = '_pmc_traffic.json' if config_name == 'metric' else f'_pmc_traffic_{config_name}.json'
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*' + suffix)), key=os.path.getmtime)
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*' + suffix)), reverse=True)
     if not files:
         return None, {"traffic_stale": f"no profiles/*{suffix}"}
-    with open(files[-1]) as f:
-        digest = json.load(f)
-    rel = os.path.relpath(files[-1], ROOT)
-    if digest.get("library_sha256") != lib_hash:
-        return None, {"traffic_stale": f"{rel} was collected with another build of the library "
-                                       f"({str(digest.get('library_sha256'))[:12]} vs loaded {lib_hash[:12]})"}
-    return digest.get("hbm_bytes_per_launch"), {"traffic_source": rel}
+    seen = []
+    for path in files:
+        with open(path) as f:
+            digest = json.load(f)
+        rel = os.path.relpath(path, ROOT)
+        if digest.get("library_sha256") != lib_hash:
+            seen.append(f"{rel} ({str(digest.get('library_sha256'))[:12]})")
+            continue
+        # digests written before the batch was recorded were collected at the config's own batch
+        digest_batch = digest.get("batch_per_gpu", CONFIGS[config_name]['B'])
+        if digest_batch != batch:
+            return None, {"traffic_stale": f"{rel} counted launches of {digest_batch} sequences, this run launches {batch}"}
+        return digest.get("hbm_bytes_per_launch"), {"traffic_source": rel}
+    return None, {"traffic_stale": "no digest was collected with the loaded build of the library "
+                                   f"({lib_hash[:12]}); on file: " + ", ".join(seen)}
 
 
 def main():
@@ -237,10 +247,28 @@ def main():
     inp = build_inputs(cfg, device, seed=rank, sets=2 if args.config == 'metric' else 4)
     nsets = len(inp['pools'])
     out = torch.empty((B, H, D), dtype=torch.bfloat16, device=device)
-    # BENCH_NATIVE_RCCL=1: the collective goes through the library's own communicator (mi355_dp_*)
-    native = dp.NativeComm(device) if use_dist and backend == 'nccl' and os.environ.get('BENCH_NATIVE_RCCL') else None
+    # How the ids are exchanged when there is more than one rank (BENCH_EXCHANGE overrides):
+    #   device (default with RCCL): the library's own communicator (mi355_dp_*) on a side stream, each
+    #          collective behind a one-wave watcher kernel that returns once the step's ids are written
+    #          (mi355_dp_exchange_*): the compute stream carries the step's three kernels and nothing
+    #          else, and no rank waits for another on it
+    #   native: the same communicator behind an event record + stream wait per step
+    #   torch : torch.distributed's all_gather_into_tensor on a side stream
+    # A mode that cannot be set up on this machine falls back to the next one; the line says which ran.
+    exchange = os.environ.get('BENCH_EXCHANGE') or ('native' if os.environ.get('BENCH_NATIVE_RCCL') else 'device')
+    if not (use_dist and backend == 'nccl'):
+        exchange = 'torch'
+    if exchange == 'device' and args.gather_every != 1:
+        exchange = 'native'
+    exchange_note = None
+    native = None
+    if exchange in ('device', 'native'):
+        try:
+            native = dp.NativeComm(device)
+        except Exception as e:   # no librccl.so.1, or the communicator did not come up
+            exchange, exchange_note = 'torch', f"library communicator unavailable ({e}); torch.distributed instead"
     gather = dp.OverlappedTokenGather(B, device, single_rank_collective=use_dist, every=args.gather_every,
-                                      native=native)
+                                      native=native, device_started=exchange == 'device')
 
     roofline_ids = torch.empty((B,), dtype=torch.int32, device=device)
     ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(ROOFLINE_LAUNCHES)]
@@ -270,29 +298,41 @@ def main():
         else:
             ops.sample_argmax(inp['logits'], out=roofline_ids)
 
+    host_issue = [0.0]     # seconds the host spent issuing the last run's steps (before waiting for anything)
+
+    def run_steps(first, count):
+        h0 = time.perf_counter()
+        for i in range(first, first + count):
+            step(i)
+        host_issue[0] = time.perf_counter() - h0
+        gather.drain()
+
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     trace('inputs built')
-    for i in range(args.warmup):
-        step(i)
-    gather.drain()
+    run_steps(0, args.warmup)
     trace('warmup issued')
     barrier()
     trace('timed region')
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    gather.drain()
+    run_steps(args.warmup, args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert gather.result(args.steps - 1).numel() == B * world
+    # every rank holds the whole batch's ids of the last step, its own slice among them
+    last = args.warmup + args.steps - 1
+    got = gather.result(last)
+    if args.steps > 0:
+        assert got.numel() == B * world
+        if args.gather_every == 1 and not os.environ.get('MI355_DP_EXCHANGE_PROBE'):   # (probes drop parts of the exchange)
+            mine = ops.sample_argmax(inp['logits'])      # (the logits are the same every step)
+            assert torch.equal(got[rank * B:(rank + 1) * B], mine), "gathered ids do not hold this rank's own"
 
     # Roofline loop (outside `value`): the same steps, the decode launch of each between two HIP
     # events on the launch stream (torch's current stream, the one ops passes to the library).  A
@@ -338,6 +378,7 @@ def main():
             "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "host_issue_ms_per_step": round(1e3 * host_issue[0] / max(args.steps, 1), 4),
             "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"paged decode step: batch={B}/GPU, ctx={S}, heads={H}, head_dim={D}, "
@@ -371,9 +412,18 @@ def main():
                              "frac": round(abytes / (sum(bracket_ms) / len(bracket_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
             "library_sha256": lib_hash,
         }
+        if use_dist:
+            line["config"]["exchange"] = {
+                "device": "library communicator (RCCL) on a side stream, started by the GPU: a one-wave watcher kernel "
+                          "returns once the step's ids are written, then the all-gather runs (no event, no wait and "
+                          "no extra launch on the compute stream)",
+                "native": "library communicator (RCCL) on a side stream behind an event record + stream wait per step",
+                "torch": "torch.distributed all_gather_into_tensor on a side stream"}[exchange]
+            if exchange_note:
+                line["config"]["exchange_note"] = exchange_note
         # HBM bytes per launch from the committed counter passes (tools/collect_profiles.sh +
         # tools/pmc_traffic.py; counters cannot be read inside this process)
-        traffic, note = measured_traffic(args.config, lib_hash)
+        traffic, note = measured_traffic(args.config, lib_hash, B)
         if args.fused_step and traffic is not None:   # the counters were collected on the two-launch step's kernel
             traffic, note = None, {"traffic_stale": "counters were collected for mi355_paged_decode, not for the append kernel"}
         line["roofline"]["traffic"] = traffic
@@ -389,6 +439,7 @@ def main():
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if native is not None:
         torch.cuda.synchronize()
+        gather.close()
         native.close()
     if use_dist:
         dist.destroy_process_group()

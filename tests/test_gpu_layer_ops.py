@@ -531,3 +531,67 @@ def test_native_rccl_communicator_one_rank(device):
     assert g.result(9).tolist() == [90 + j for j in range(8)]
     assert g.result(7).tolist() == [70 + j for j in range(8)]
     comm.close()
+
+
+def test_exchange_started_by_the_gpu_one_rank(ops, device):
+    """mi355_dp_exchange_* on a one-rank RCCL communicator: each all-gather sits on the library's side
+    stream behind a watcher kernel that returns once the step's ids are written; the compute stream
+    only runs the plain sampler.  The ids of step i must be in result(i) -- never those of an earlier
+    or later step -- over 50 steps whose logits change every step, with a long kernel queued ahead
+    so that the host runs far ahead of the device (and is held back by the buffer ring, not the
+    stream); afterwards every send buffer is marked "not written" again."""
+    from mi355_paged import dp
+    comm = dp.NativeComm(device)
+    B, V = 256, 4096
+    gather = dp.OverlappedTokenGather(B, device, single_rank_collective=True, native=comm)
+    assert gather.watcher
+    assert all(bool((s == -1).all()) for s in gather.send)
+    g = torch.Generator(device='cpu').manual_seed(5)
+    logits = [torch.randn((B, V), generator=g).to(device) for _ in range(5)]
+    want = [l.argmax(dim=1).to(torch.int32) for l in logits]
+    torch.cuda._sleep(20_000_000)
+    kept = {}
+    for i in range(50):
+        ops.sample_argmax(logits[i % 5], out=gather.send_buffer(i))
+        gather.launch(i)
+        if i >= 2:      # results stay valid for SLOTS - 1 further steps
+            kept[i - 2] = gather.result(i - 2).clone()
+    gather.drain()
+    kept[48], kept[49] = gather.result(48).clone(), gather.result(49).clone()
+    torch.cuda.synchronize()
+    for i in range(50):
+        assert torch.equal(kept[i], want[i % 5]), i
+    assert all(bool((s == -1).all()) for s in gather.send)
+    # ids written by a kernel of another library (a torch copy) start the exchange just the same
+    for i in range(50, 60):
+        gather.send_buffer(i).copy_(want[i % 5] + i)
+        gather.launch(i)
+    gather.drain()
+    assert torch.equal(gather.result(59), want[59 % 5] + 59) and torch.equal(gather.result(57), want[57 % 5] + 57)
+    # the form with one event record (no system fence) per exchange on the compute stream
+    plain = dp.OverlappedTokenGather(B, device, single_rank_collective=True, native=comm, device_started=False)
+    assert not plain.watcher
+    ops.sample_argmax(logits[0], out=plain.send_buffer(0))
+    plain.launch(0)
+    plain.drain()
+    assert torch.equal(plain.result(0), want[0])
+    gather.close()
+    comm.close()
+
+
+def test_exchange_fed_from_host_vectors_one_rank(device):
+    """OverlappedTokenGather.host_buffer / launch_from_host with the library's communicator: the
+    upload and the collective replay as one graph per buffer pair on the side stream."""
+    from mi355_paged import dp
+    comm = dp.NativeComm(device)
+    gather = dp.OverlappedTokenGather(33, device, single_rank_collective=True, native=comm)
+    for i in range(21):
+        host = gather.host_buffer(i)
+        host.copy_(torch.arange(33, dtype=torch.int32) + 100 * i)
+        gather.launch_from_host(i)
+        if i >= 1:
+            assert gather.result(i - 1).cpu().tolist() == [100 * (i - 1) + j for j in range(33)]
+    gather.drain()
+    assert gather.result(20).cpu().tolist() == [2000 + j for j in range(33)]
+    assert gather._host_graphs, "the exchange was not captured"
+    comm.close()

@@ -38,6 +38,7 @@ enum Knob {
   kKnobPrefillF32Mfma,    // MI355_PREFILL_F32_MFMA    1: fp32 prompts (head_dim 32 / 64 / 128) on the fp32 matrix instruction
   kKnobDecodeFusedMerge,  // MI355_DECODE_FUSED_MERGE  most token splits the VALU decode kernel merges in its own launch (0: never)
   kKnobPagedBalanceWgs,   // MI355_PAGED_BALANCE_WGS   workgroups a decode launch spreads its kv heads over for ragged batches (0: off)
+  kKnobDpExchangeProbe,   // MI355_DP_EXCHANGE_PROBE   measurement only, bit mask: 1 no collective, 2 no completion event, 4 no watcher
   kKnobCount
 };
 int knob(Knob k);
@@ -296,6 +297,17 @@ __device__ __forceinline__ void split_block_index(int b, int n_ht, int nsplit, i
   }
   sp = item % nsplit;
   row = item / nsplit;
+}
+
+// Waits until every store this wave has issued has been acknowledged by the memory system
+// (s_waitcnt vmcnt(0); stores count in vmcnt until they are).  After it, a value the wave wrote
+// with an agent-scope atomic store (written through the XCD's L2) is in device-coherent memory.
+// The immediate is the gfx9-family encoding of vmcnt(0) with the other counters left alone.
+__device__ __forceinline__ void wait_stores_acknowledged() {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
+#error "s_waitcnt immediate below encodes vmcnt(0) for gfx942 / gfx950 only"
+#endif
+  __builtin_amdgcn_s_waitcnt(0x0F70);
 }
 
 template <bool NT>

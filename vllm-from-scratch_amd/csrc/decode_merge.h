@@ -51,7 +51,7 @@ __device__ inline bool arrived_last(const DecodeParams& p, int b, int hg, int qc
   // every wave's partials have been written through (vmcnt counts stores until they are
   // acknowledged) before the workgroup's arrival is counted
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+  wait_stores_acknowledged();
   __syncthreads();
   if (tid == 0) {
     unsigned long long* cell = arrival_cell(p, b, hg, qc);

@@ -50,6 +50,58 @@ int rccl_fail(const char* what, int rc) {
   return fail(MI355_ECOLLECTIVE, "%s: %s (rccl result %d)", what, r.GetErrorString ? r.GetErrorString(rc) : "error", rc);
 }
 
+// A device-started exchange: the collective sits on a side stream of its own behind a one-wave
+// "watcher" kernel that returns once every id of the step has been written.  The producer's
+// stream carries nothing for the exchange: no event record, no wait, no extra launch, and the
+// sampler is the plain one.  Ids are non-negative; a send buffer holds kNotWritten in every entry
+// the watcher has not seen written yet, and is marked again right after its collective.
+constexpr int kExchangeSlots = 8;
+constexpr int32_t kNotWritten = -1;
+constexpr long long kWatchTicks = 10ll * 100000000ll;   // the watcher gives up after 10 s (100 MHz clock)
+
+struct Exchange {
+  void* comm = nullptr;
+  int device = -1;
+  hipStream_t side = nullptr;
+  int* gave_up = nullptr;                   // pinned host memory, raised by a watcher that timed out
+  hipEvent_t done[kExchangeSlots] = {};
+  hipEvent_t ready[kExchangeSlots] = {};    // recorded on the producer's stream (no system fence)
+  bool recorded[kExchangeSlots] = {};
+};
+
+// One wave.  Agent-scope loads go past the XCD's L2 to device-coherent memory, where the
+// producer's ids land when its kernel ends; between polls the wave sleeps.
+__global__ void __launch_bounds__(64) watch_ids_kernel(const int32_t* ids, int64_t count, int* gave_up, int naps) {
+  const long long t0 = wall_clock64();
+  for (;;) {
+    bool written = true;
+    for (int64_t i = threadIdx.x; i < count; i += 64)
+      written &= __hip_atomic_load(ids + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kNotWritten;
+    if (__all(written)) return;
+    if (wall_clock64() - t0 > kWatchTicks) {
+      if (threadIdx.x == 0) __hip_atomic_store(gave_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+    if (naps == 0) __builtin_amdgcn_s_sleep(32);
+    for (int k = 0; k < naps; ++k) __builtin_amdgcn_s_sleep(127);
+  }
+}
+
+__global__ void mark_ids_kernel(int32_t* ids, int64_t count) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) ids[i] = kNotWritten;
+}
+
+int hip_fail(const char* what, hipError_t e) {
+  fail((int)e, "%s: %s", what, hipGetErrorString(e));
+  return (int)e;
+}
+
+int mark(Exchange* x, int32_t* ids, int64_t count) {
+  hipLaunchKernelGGL(mark_ids_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, x->side, ids, count);
+  return check_launch("mark_ids_kernel");
+}
+
 }  // namespace
 }  // namespace mi355
 
@@ -91,5 +143,116 @@ extern "C" int mi355_dp_destroy(void* comm) {
   const Rccl& r = rccl();
   if (!r.ok) return fail(MI355_EUNSUPPORTED, "dp_destroy: librccl.so.1 is not available");
   if (int rc = r.CommDestroy(comm)) return rccl_fail("ncclCommDestroy", rc);
+  return 0;
+}
+
+extern "C" int mi355_dp_exchange_create(void* comm, void** exchange_out) {
+  if (!comm || !exchange_out) return fail(MI355_EINVAL, "dp_exchange_create: null pointer");
+  Exchange* x = new Exchange;
+  x->comm = comm;
+  hipError_t e = hipGetDevice(&x->device);
+  if (!e) e = hipStreamCreateWithFlags(&x->side, hipStreamNonBlocking);
+  if (!e) e = hipHostMalloc(reinterpret_cast<void**>(&x->gave_up), sizeof(int), hipHostMallocMapped);
+  if (!e) *x->gave_up = 0;
+  for (int i = 0; i < kExchangeSlots && !e; ++i) e = hipEventCreateWithFlags(&x->done[i], hipEventDisableTiming);
+  for (int i = 0; i < kExchangeSlots && !e; ++i)
+    e = hipEventCreateWithFlags(&x->ready[i], hipEventDisableTiming | hipEventDisableSystemFence);
+  if (e) {
+    mi355_dp_exchange_destroy(x);
+    return hip_fail("dp_exchange_create", e);
+  }
+  *exchange_out = x;
+  return 0;
+}
+
+extern "C" int mi355_dp_exchange_arm(void* exchange, int32_t* send, int64_t count) {
+  Exchange* x = static_cast<Exchange*>(exchange);
+  if (!x || !send || count <= 0) return fail(MI355_EINVAL, "dp_exchange_arm: bad argument");
+  if (int rc = mark(x, send, count)) return rc;
+  if (hipError_t e = hipStreamSynchronize(x->side)) return hip_fail("hipStreamSynchronize", e);
+  return 0;
+}
+
+extern "C" int mi355_dp_exchange_launch(void* exchange, int32_t* send, int32_t* recv, int64_t count, int32_t slot) {
+  Exchange* x = static_cast<Exchange*>(exchange);
+  if (!x || !send || !recv || count <= 0 || slot < 0 || slot >= kExchangeSlots)
+    return fail(MI355_EINVAL, "dp_exchange_launch: bad argument");
+  const Rccl& r = rccl();
+  if (!r.ok) return fail(MI355_EUNSUPPORTED, "dp_exchange_launch: librccl.so.1 is not available");
+  const int probe = knob(kKnobDpExchangeProbe);
+  if (!(probe & 4)) {
+    hipLaunchKernelGGL(watch_ids_kernel, dim3(1), dim3(64), 0, x->side, send, count, x->gave_up, (probe >> 8) & 0xff);
+    if (int rc = check_launch("watch_ids_kernel")) return rc;
+  }
+  if (!(probe & 1))
+    if (int rc = r.AllGather(send, recv, (size_t)count, kNcclInt32, x->comm, x->side)) return rccl_fail("ncclAllGather", rc);
+  if (int rc = mark(x, send, count)) return rc;
+  if (probe & 2) return 0;
+  if (hipError_t e = hipEventRecord(x->done[slot], x->side)) return hip_fail("hipEventRecord", e);
+  x->recorded[slot] = true;
+  return 0;
+}
+
+extern "C" int mi355_dp_exchange_launch_after(void* exchange, void* producer_stream, const int32_t* send,
+                                              int32_t* recv, int64_t count, int32_t slot) {
+  Exchange* x = static_cast<Exchange*>(exchange);
+  if (!x || !send || !recv || count <= 0 || slot < 0 || slot >= kExchangeSlots)
+    return fail(MI355_EINVAL, "dp_exchange_launch_after: bad argument");
+  const Rccl& r = rccl();
+  if (!r.ok) return fail(MI355_EUNSUPPORTED, "dp_exchange_launch_after: librccl.so.1 is not available");
+  const int probe = knob(kKnobDpExchangeProbe);
+  if (!(probe & 8))
+    if (hipError_t e = hipEventRecord(x->ready[slot], static_cast<hipStream_t>(producer_stream))) return hip_fail("hipEventRecord", e);
+  if (!(probe & 12))
+    if (hipError_t e = hipStreamWaitEvent(x->side, x->ready[slot], 0)) return hip_fail("hipStreamWaitEvent", e);
+  if (!(probe & 1))
+    if (int rc = r.AllGather(send, recv, (size_t)count, kNcclInt32, x->comm, x->side)) return rccl_fail("ncclAllGather", rc);
+  if (probe & 2) return 0;
+  if (hipError_t e = hipEventRecord(x->done[slot], x->side)) return hip_fail("hipEventRecord", e);
+  x->recorded[slot] = true;
+  return 0;
+}
+
+static int exchange_gave_up(Exchange* x) {
+  if (!*reinterpret_cast<volatile int*>(x->gave_up)) return 0;
+  return fail(MI355_ECOLLECTIVE, "dp_exchange: a step's ids were not written within 10 s of its exchange being due; "
+                                 "what was gathered for it is not valid");
+}
+
+extern "C" int mi355_dp_exchange_done(void* exchange, int32_t slot) {
+  Exchange* x = static_cast<Exchange*>(exchange);
+  if (!x || slot < 0 || slot >= kExchangeSlots) return fail(MI355_EINVAL, "dp_exchange_done: bad argument");
+  if (!x->recorded[slot]) return 1;
+  const hipError_t e = hipEventQuery(x->done[slot]);
+  if (e == hipErrorNotReady) return 0;
+  if (e != hipSuccess) return fail(MI355_ECOLLECTIVE, "dp_exchange_done: %s", hipGetErrorString(e));
+  if (int rc = exchange_gave_up(x)) return rc;
+  return 1;
+}
+
+extern "C" int mi355_dp_exchange_wait(void* exchange, int32_t slot, void* stream, int32_t host) {
+  Exchange* x = static_cast<Exchange*>(exchange);
+  if (!x || slot < 0 || slot >= kExchangeSlots) return fail(MI355_EINVAL, "dp_exchange_wait: bad argument");
+  if (!x->recorded[slot]) return 0;
+  if (host) {
+    if (hipError_t e = hipEventSynchronize(x->done[slot])) return hip_fail("hipEventSynchronize", e);
+    return exchange_gave_up(x);
+  }
+  if (hipError_t e = hipStreamWaitEvent(static_cast<hipStream_t>(stream), x->done[slot], 0))
+    return hip_fail("hipStreamWaitEvent", e);
+  return 0;
+}
+
+extern "C" int mi355_dp_exchange_destroy(void* exchange) {
+  Exchange* x = static_cast<Exchange*>(exchange);
+  if (!x) return 0;
+  if (x->side) (void)hipStreamSynchronize(x->side);    // a watcher still waiting returns within its time limit
+  for (int i = 0; i < kExchangeSlots; ++i)
+    if (x->done[i]) (void)hipEventDestroy(x->done[i]);
+  for (int i = 0; i < kExchangeSlots; ++i)
+    if (x->ready[i]) (void)hipEventDestroy(x->ready[i]);
+  if (x->gave_up) (void)hipHostFree(x->gave_up);
+  if (x->side) (void)hipStreamDestroy(x->side);
+  delete x;
   return 0;
 }

@@ -67,6 +67,13 @@ SIGNATURES = {
     'mi355_dp_init': (c_int, [c_void_p, c_int32, c_int32, c_void_p]),
     'mi355_dp_allgather_i32': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     'mi355_dp_destroy': (c_int, [c_void_p]),
+    'mi355_dp_exchange_create': (c_int, [c_void_p, c_void_p]),
+    'mi355_dp_exchange_arm': (c_int, [c_void_p, c_void_p, c_int64]),
+    'mi355_dp_exchange_launch': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32]),
+    'mi355_dp_exchange_launch_after': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32]),
+    'mi355_dp_exchange_done': (c_int, [c_void_p, c_int32]),
+    'mi355_dp_exchange_wait': (c_int, [c_void_p, c_int32, c_void_p, c_int32]),
+    'mi355_dp_exchange_destroy': (c_int, [c_void_p]),
     'mi355_debug_set_knob': (c_int, [c_char_p, c_int32]),
     'mi355_silu_mul': (c_int, [
         c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p]),

@@ -100,10 +100,95 @@ class NativeComm:
             self._check(self._lib.mi355_dp_allgather_i32(self._comm, send.data_ptr(), recv.data_ptr(),
                                                          send.numel(), stream.cuda_stream), 'mi355_dp_allgather_i32')
 
+    def device_started_exchange(self) -> "DeviceStartedExchange":
+        """An exchange the GPU starts by itself once a step's ids are written (mi355_dp_exchange_*)."""
+        return DeviceStartedExchange(self)
+
     def close(self) -> None:
         if self._comm is not None and self._comm.value:
             self._check(self._lib.mi355_dp_destroy(self._comm), 'mi355_dp_destroy')
         self._comm = None
+
+
+class DeviceStartedExchange:
+    """mi355_dp_exchange_*: the all-gather runs on a side stream the library owns, behind a one-wave
+    watcher kernel that returns once every id of the step has been written; afterwards the send
+    buffer is marked "not written" (-1) again.  The stream that samples carries nothing for the
+    exchange -- no event record, no wait, no extra launch -- and its sampler is the plain one.
+    Ids must be non-negative."""
+
+    SLOTS = 8
+
+    def __init__(self, comm: NativeComm):
+        import ctypes
+        self.comm, self._lib, self._check = comm, comm._lib, comm._check
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(comm.device):
+            self._check(self._lib.mi355_dp_exchange_create(comm._comm, ctypes.byref(handle)), 'mi355_dp_exchange_create')
+        self._x = handle
+
+    def _vectors(self, send, recv=None):
+        ok = send.dtype == torch.int32 and send.is_cuda and send.is_contiguous()
+        if recv is not None:
+            ok = ok and recv.dtype == torch.int32 and recv.is_cuda and recv.is_contiguous() \
+                and recv.numel() == send.numel() * self.comm.world
+        if not ok:
+            raise ValueError("send / recv must be contiguous int32 device vectors, recv world times as long")
+
+    def arm(self, send: torch.Tensor) -> None:
+        """Marks a send buffer as not written, once, before the first launch that reads it (synchronous)."""
+        self._vectors(send)
+        with torch.cuda.device(self.comm.device):
+            self._check(self._lib.mi355_dp_exchange_arm(self._x, send.data_ptr(), send.numel()), 'mi355_dp_exchange_arm')
+
+    def launch(self, send: torch.Tensor, recv: torch.Tensor, slot: int) -> None:
+        """All-gather `send` into `recv` as soon as every entry of `send` has been written."""
+        self._vectors(send, recv)
+        with torch.cuda.device(self.comm.device):
+            self._check(self._lib.mi355_dp_exchange_launch(self._x, send.data_ptr(), recv.data_ptr(), send.numel(), slot),
+                        'mi355_dp_exchange_launch')
+
+    def launch_after(self, send: torch.Tensor, recv: torch.Tensor, slot: int, stream=None) -> None:
+        """All-gather `send` into `recv` once `stream` (default: current) has reached this point: one
+        event record without a system fence on that stream, everything else on the side stream."""
+        self._vectors(send, recv)
+        stream = stream if stream is not None else torch.cuda.current_stream(self.comm.device)
+        with torch.cuda.device(self.comm.device):
+            self._check(self._lib.mi355_dp_exchange_launch_after(self._x, stream.cuda_stream, send.data_ptr(),
+                                                                 recv.data_ptr(), send.numel(), slot),
+                        'mi355_dp_exchange_launch_after')
+
+    def done(self, slot: int) -> bool:
+        rc = self._lib.mi355_dp_exchange_done(self._x, slot)
+        if rc < 0:
+            self._check(rc, 'mi355_dp_exchange_done')
+        return rc == 1
+
+    def wait(self, slot: int, host: bool = False) -> None:
+        stream = torch.cuda.current_stream(self.comm.device).cuda_stream
+        with torch.cuda.device(self.comm.device):
+            self._check(self._lib.mi355_dp_exchange_wait(self._x, slot, stream, 1 if host else 0), 'mi355_dp_exchange_wait')
+
+    def close(self) -> None:
+        if self._x is not None and self._x.value:
+            self._check(self._lib.mi355_dp_exchange_destroy(self._x), 'mi355_dp_exchange_destroy')
+        self._x = None
+
+
+class _SlotWork:
+    """A DeviceStartedExchange slot as the collective handle OverlappedTokenGather keeps per buffer pair."""
+
+    def __init__(self, exchange: DeviceStartedExchange, slot: int):
+        self.exchange, self.slot = exchange, slot
+
+    def is_completed(self) -> bool:
+        return self.exchange.done(self.slot)
+
+    def wait(self) -> None:
+        self.exchange.wait(self.slot)
+
+    def host_wait(self) -> None:
+        self.exchange.wait(self.slot, host=True)
 
 
 class _EventWork:
@@ -118,6 +203,9 @@ class _EventWork:
 
     def wait(self) -> None:
         torch.cuda.current_stream(self.device).wait_event(self.event)
+
+    def host_wait(self) -> None:
+        self.event.synchronize()
 
 
 class OverlappedTokenGather:
@@ -141,12 +229,16 @@ class OverlappedTokenGather:
     SLOTS = 4
 
     def __init__(self, n_local: int, device, dtype=torch.int32, group=None, single_rank_collective=False,
-                 every: int = 1, native: Optional[NativeComm] = None):
+                 every: int = 1, native: Optional[NativeComm] = None, device_started: bool = True):
         """`every` > 1 batches the exchange: the ids of `every` consecutive steps travel in one
         collective, issued after the last of them (or by `flush()` / `drain()`), so its fixed cost
         (a host call, a kernel and two stream dependencies) is paid once per group of steps.
-        `native`: a NativeComm to run the collective through (on a side stream of its own) instead
-        of torch.distributed."""
+        `native`: a NativeComm to run the collective through, on a side stream of the library's
+        (mi355_dp_exchange_*), instead of torch.distributed.  With `device_started` (the default;
+        one step per collective, ids non-negative) the GPU starts each collective itself once the
+        step's ids are written and the compute stream carries nothing for the exchange;
+        `device_started=False` puts one event record (without a system fence) per exchange on the
+        compute stream instead."""
         if every < 1:
             raise ValueError(f"every must be >= 1, got {every}")
         self.group = group
@@ -156,10 +248,15 @@ class OverlappedTokenGather:
         self.world = dist.get_world_size(group) if self.active else 1
         self.native = native
         self.side = None
+        self.device_started: Optional[DeviceStartedExchange] = None
         if native is not None:
             if dtype != torch.int32:
                 raise ValueError("the native collective moves int32 ids")
             self.active, self.world = native.world > 1 or single_rank_collective, native.world
+            if self.active:
+                self.device_started = native.device_started_exchange()
+            # (created after the library's side stream: with few hardware queues per process the
+            # streams made first are the ones that get a queue of their own)
             self.side = torch.cuda.Stream(device=device)
         # gloo cannot move device memory: stage through the host, synchronously (CPU tests, rehearsals)
         self.host_staged = (self.active and native is None and dist.get_backend(group) == 'gloo'
@@ -171,6 +268,13 @@ class OverlappedTokenGather:
                      else None for _ in range(self.SLOTS)]
         self.work = [None] * self.SLOTS
         self.pending = [False] * self.SLOTS      # written by send_buffer users, not yet exchanged
+        self._host = None                        # host_buffer(): one staging vector per buffer pair
+        self._host_copied = [None] * self.SLOTS  # event behind the last upload of each staging vector
+        self._host_graphs = None                 # launch_from_host(): captured upload + collective per pair
+        self.watcher = device_started and every == 1      # else: an event record per exchange
+        if self.device_started is not None and self.watcher:
+            for send in self.send:
+                self.device_started.arm(send)
 
     def _slot(self, step: int) -> int:
         return (step // self.every) % self.SLOTS
@@ -179,6 +283,12 @@ class OverlappedTokenGather:
         slot, j = self._slot(step), step % self.every
         if j == 0 or not self.pending[slot]:
             work = self.work[slot]
+            if work is not None and not work.is_completed() and hasattr(work, 'host_wait'):
+                # The host has run SLOTS exchanges ahead of the device.  It waits here itself -- the
+                # device still has the steps in between queued -- instead of putting a wait on the
+                # compute stream, which would cost that stream several microseconds on every step
+                # from then on (a host that issues steps faster than the device runs them stays ahead).
+                work.host_wait()
             if work is not None and work.is_completed():
                 self.work[slot] = None
             self._wait(slot)
@@ -190,6 +300,71 @@ class OverlappedTokenGather:
         if step % self.every == self.every - 1:
             self._exchange(self._slot(step))
 
+    def host_buffer(self, step: int) -> torch.Tensor:
+        """Host-side staging vector of step `step`'s buffer pair (pinned when the ids travel from
+        device memory), for front ends whose ids are host values: fill it, then `launch_from_host`.
+        It may be rewritten once its last upload is over, which this call waits for."""
+        if self.every != 1:
+            raise ValueError("host staging serves one step per collective")
+        slot = self._slot(step)
+        if self._host is None:
+            pin = self.send[0].is_cuda
+            self._host = [torch.zeros((self.n_local,), dtype=self.send[0].dtype, pin_memory=pin)
+                          for _ in range(self.SLOTS)]
+        copied = self._host_copied[slot]
+        if copied is not None:
+            copied.synchronize()
+            self._host_copied[slot] = None
+        return self._host[slot]
+
+    def launch_from_host(self, step: int) -> None:
+        """Uploads `host_buffer(step)` and exchanges it.  With the library's communicator the upload
+        and the collective are one HIP graph per buffer pair, replayed on the side stream: the
+        compute stream is not involved at all and the host makes one graph launch."""
+        slot = self._slot(step)
+        host = self._host[slot]
+        if self.native is None or not self.active:
+            self.send_buffer(step).copy_(host, non_blocking=True)
+            if host.is_pinned():
+                self._host_copied[slot] = torch.cuda.Event()
+                self._host_copied[slot].record()
+            self.launch(step)
+            return
+        dev = self.native.device
+        if self._host_graphs is None:
+            self._host_graphs = self._capture_host_exchanges()
+        with torch.cuda.stream(self.side):
+            if self._host_graphs:
+                self._host_graphs[slot].replay()
+            else:
+                self.send[slot].copy_(host, non_blocking=True)
+                self.native.all_gather_i32(self.send[slot], self.recv[slot], stream=self.side)
+            done = torch.cuda.Event()
+            done.record(self.side)
+        self.work[slot] = _EventWork(done, dev)
+        self._host_copied[slot] = done
+
+    def _capture_host_exchanges(self):
+        """One graph per buffer pair: pinned host vector -> send buffer -> all-gather.  An empty
+        list (eager calls instead) when the capture is refused."""
+        graphs = []
+        try:
+            with torch.cuda.stream(self.side):
+                for slot in range(self.SLOTS):       # first use of the communicator outside a capture
+                    self.native.all_gather_i32(self.send[slot], self.recv[slot], stream=self.side)
+                self.side.synchronize()
+                for slot in range(self.SLOTS):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=self.side, capture_error_mode='thread_local'):
+                        self.send[slot].copy_(self._host[slot], non_blocking=True)
+                        self.native.all_gather_i32(self.send[slot], self.recv[slot],
+                                                   stream=torch.cuda.current_stream(self.native.device))
+                    graphs.append(g)
+        except Exception:
+            torch.cuda.synchronize(self.native.device)
+            return []
+        return graphs
+
     def flush(self) -> None:
         """Exchanges a group that is only partly filled (the end of a run)."""
         for slot in range(self.SLOTS):
@@ -200,13 +375,13 @@ class OverlappedTokenGather:
         self.pending[slot] = False
         if not self.active:
             return
-        if self.native is not None:
-            dev = self.native.device
-            self.side.wait_stream(torch.cuda.current_stream(dev))      # the sampler has written the ids
-            self.native.all_gather_i32(self.send[slot], self.recv[slot], stream=self.side)
-            done = torch.cuda.Event()
-            done.record(self.side)
-            self.work[slot] = _EventWork(done, dev)
+        if self.device_started is not None:
+            # the library's side stream watches the ids arrive, then gathers and marks the buffer again
+            if self.watcher:
+                self.device_started.launch(self.send[slot], self.recv[slot], slot)
+            else:
+                self.device_started.launch_after(self.send[slot], self.recv[slot], slot)
+            self.work[slot] = _SlotWork(self.device_started, slot)
             return
         if self.host_staged:
             out = torch.empty((self.recv[slot].numel(),), dtype=self.recv[slot].dtype)
@@ -226,8 +401,10 @@ class OverlappedTokenGather:
         ready.record()
         self.side.wait_event(ready)
         with torch.cuda.stream(self.side):
-            self.work[slot] = dist.all_gather_into_tensor(self.recv[slot], self.send[slot], group=self.group,
-                                                          async_op=True)
+            dist.all_gather_into_tensor(self.recv[slot], self.send[slot], group=self.group, async_op=True).wait()
+            done = torch.cuda.Event()       # (wait() above orders the side stream behind the collective)
+            done.record(self.side)
+        self.work[slot] = _EventWork(done, self.send[slot].device)
 
     def _wait(self, slot: int) -> None:
         if self.work[slot] is not None:
@@ -252,3 +429,9 @@ class OverlappedTokenGather:
         self.flush()
         for slot in range(self.SLOTS):
             self._wait(slot)
+
+    def close(self) -> None:
+        """Releases the GPU-started exchange, if any (before the communicator is closed)."""
+        if self.device_started is not None:
+            self.device_started.close()
+            self.device_started = None

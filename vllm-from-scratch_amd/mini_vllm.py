@@ -1652,7 +1652,9 @@ class DataParallelMiniVLLM:
     list of prompts: a request's tokens depend only on its own prompt and the weights.
     """
 
-    def __init__(self, group=None, **engine_kwargs):
+    def __init__(self, group=None, single_rank_collective: bool = False, **engine_kwargs):
+        """`single_rank_collective`: issue the per-step collective on a one-rank group too (a rehearsal of
+        the RCCL path on a one-GPU machine); `engine_kwargs` are MiniVLLM's."""
         import torch.distributed as dist
         from mi355_paged import dp
         self._dp = dp
@@ -1668,12 +1670,19 @@ class DataParallelMiniVLLM:
         if self.world > 1:
             self._replicate_weights(dist, backend)
         self.cap = self.engine.scheduler.max_num_seqs
-        self._gather = dp.OverlappedTokenGather(2 * self.cap + 1, self._wire_device, group=group)
-        # one staging vector per buffer pair of the gather: a vector is rewritten only after the
-        # collective that read its previous contents has been waited for
-        self._host = [torch.zeros((2 * self.cap + 1,), dtype=torch.int32) for _ in range(self._gather.SLOTS)]
-        if self._wire_device.type == 'cuda':
-            self._host = [h.pin_memory() for h in self._host]
+        # Over RCCL the exchange runs through the library's own communicator: the upload of a step's
+        # vector and its all-gather are one captured graph per buffer pair, replayed on a side
+        # stream (one graph launch per engine step on the host, nothing on the compute stream).
+        # Where the communicator cannot be set up, torch.distributed carries the collective.
+        self._native = None
+        if backend == 'nccl' and (self.world > 1 or single_rank_collective):
+            try:
+                self._native = dp.NativeComm(self.engine.device, group)
+            except Exception:
+                self._native = None
+        self._gather = dp.OverlappedTokenGather(2 * self.cap + 1, self._wire_device, group=group,
+                                                single_rank_collective=single_rank_collective, native=self._native,
+                                                device_started=False)    # the vectors come from the host
 
     def _replicate_weights(self, dist, backend) -> None:
         """Every rank takes rank 0's parameters and tables (the KV buffers are per-rank state)."""
@@ -1722,14 +1731,13 @@ class DataParallelMiniVLLM:
             results = self.engine.step() if self.engine.scheduler.has_unfinished else []
             if len(results) > cap:
                 raise RuntimeError(f"a step produced {len(results)} tokens for {cap} sequence slots")
-            host = self._host[step % len(self._host)]
+            host = gather.host_buffer(step)
             host.fill_(-1)
             for j, (rid, tok) in enumerate(results):
                 host[2 * j] = local_index[rid]
                 host[2 * j + 1] = tok
             host[2 * cap] = 1 if self.engine.scheduler.has_unfinished else 0
-            gather.send_buffer(step).copy_(host, non_blocking=True)
-            gather.launch(step)
+            gather.launch_from_host(step)
             # step - 1's collective has had a whole engine step to complete
             if step >= 1 and consume(step - 1):
                 break
