@@ -166,6 +166,33 @@ int mi355_paged_decode_append(void* out, const void* q, int64_t q_stride_seq,
                               void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * mi355_paged_decode_append with the rotary embedding of the step applied on the way: q and
+ * k_new arrive UN-rotated, as the fused projection left them, and the kernel rotates both for
+ * position context_lens[b] - 1 (the new token's) before use; the rotated K row is what the cache
+ * receives.  The whole decode branch of SelfAttention.forward after the projection --
+ * 05_mini_vllm/mini_vllm.py:415-419 (cos/sin gather, rotate_half), :421-427 (cache write) and
+ * :460-481 (attention) -- in one launch; equals mi355_rope_kv_write (positions = context - 1,
+ * slots = that position's) followed by mi355_paged_decode bit for bit, caches included (the
+ * rotation is two fp32 products and a sum rounded once, in both).  q itself is left un-rotated.
+ *   cos_table, sin_table   [table_len, D] in the cache's dtype (cos[t][i] == cos[t][i + D/2]);
+ *                          positions beyond the table use its last row
+ * Shapes that mi355_paged_decode_append serves with a separate cache-write launch (the
+ * matrix-core kernel's grouped-query shapes, plans whose LDS is full) return MI355_EUNSUPPORTED
+ * before anything is launched: use mi355_rope_kv_write + mi355_paged_decode there.
+ */
+int mi355_paged_decode_append_rope(void* out, const void* q, int64_t q_stride_seq,
+                                   const void* k_new, const void* v_new, int64_t new_stride_seq,
+                                   void* k_cache, void* v_cache,
+                                   const int32_t* block_tables, const int32_t* context_lens,
+                                   const void* cos_table, const void* sin_table, int32_t table_len,
+                                   int32_t B, int32_t Hq, int32_t Hkv, int32_t D,
+                                   int32_t block_size, int32_t max_blocks, int32_t num_blocks,
+                                   int32_t max_context,
+                                   int64_t kv_stride_block, int64_t kv_stride_head, int64_t kv_stride_tok,
+                                   float scale, int32_t dtype,
+                                   void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * Scatter T new K/V rows into the paged caches by flat slot id
  * (slot = block*block_size + row).  Replaces the per-token write loops
  * 01_paged_attention/paged_attention.py:118-123, KVCachePool.write_kv (:48-51)

@@ -174,6 +174,41 @@ def test_engine_graph_decode_equals_eager(device, dtype):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('graphs', [False, True])
+def test_engine_fused_decode_step_equals_rope_write_then_attention(device, dtype, graphs):
+    """A layer's decode branch as ONE launch (RoPE of q and k, cache write and attention:
+    mi355_paged_decode_append_rope) against the two launches it replaces: the same logits, bit for
+    bit, at every step, the same tokens, and the same cache contents at the end of the run."""
+    import mini_vllm as mv
+    rng = np.random.default_rng(41)
+    prompts = [[int(t) for t in rng.integers(1, 300, size=int(n))] for n in (5, 17, 9, 30, 2, 12, 8, 21, 3)]
+    max_new = [12, 30, 7, 19, 25, 4, 16, 9, 30]
+    calls = {'fused': 0}
+    from mi355_paged import ops as _ops
+    inner = _ops.paged_decode_append
+
+    def counting(*a, **k):
+        calls['fused'] += 1 if k.get('rope') is not None else 0
+        return inner(*a, **k)
+
+    _ops.paged_decode_append = counting
+    mixed_supported = mv.MiniVLLM._mixed_supported
+    if not graphs:      # the planned eager path (steps at their own sizes) instead of the bucketed step bodies
+        mv.MiniVLLM._mixed_supported = lambda self: False
+    try:
+        two, out_two, steps_two = _run(mv, graphs, dtype, prompts, max_new, fused_decode_step=False, decode_lookahead=False)
+        assert calls['fused'] == 0
+        one, out_one, steps_one = _run(mv, graphs, dtype, prompts, max_new, fused_decode_step=True, decode_lookahead=False)
+        assert calls['fused'] > 0, "the fused launch was never taken"
+    finally:
+        _ops.paged_decode_append = inner
+        mv.MiniVLLM._mixed_supported = mixed_supported
+    assert out_one == out_two and steps_one == steps_two
+    assert torch.equal(one.model.k_cache.view(torch.uint8), two.model.k_cache.view(torch.uint8))
+    assert torch.equal(one.model.v_cache.view(torch.uint8), two.model.v_cache.view(torch.uint8))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_engine_lookahead_decode_equals_step_by_step(device, dtype):
     """The engine that issues the next decode step before reading the current one's tokens emits,
     per request, exactly the tokens of the step-by-step engines -- over a run in which requests end

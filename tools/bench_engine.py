@@ -12,7 +12,8 @@ nseq, plen, ntok, budget = ([int(x) for x in sys.argv[1:]] + [128, 256, 32, 8192
 torch.manual_seed(0)
 eng = mv.MiniVLLM(vocab_size=32000, hidden_size=512, num_layers=4, num_heads=8, intermediate_size=1536,
                   num_kv_blocks=nseq * ((plen + ntok) // 16 + 2), block_size=16, max_num_seqs=nseq,
-                  max_num_batched_tokens=budget, device='cuda', dtype=torch.bfloat16)
+                  max_num_batched_tokens=budget, device='cuda', dtype=torch.bfloat16,
+                  fused_decode_step=os.environ.get('ENGINE_FUSED_DECODE', '1') != '0')
 g = torch.Generator().manual_seed(1)
 for _ in range(2):   # first pass warms up kernels / allocator
     for i in range(nseq):
@@ -36,5 +37,5 @@ for _ in range(2):   # first pass warms up kernels / allocator
 dec_steps = steps - prefill_steps
 print(f"{nseq} seqs x ({plen} prompt + {ntok} new): total {t1 - t0:.3f} s, {produced / (t1 - t0):.0f} tok/s; "
       f"prefill {prefill_steps} steps {t_decode - t0:.3f} s ({nseq * plen / (t_decode - t0):.0f} prompt tok/s); "
-      f"decode {dec_steps} steps, {(t1 - t_decode) / max(dec_steps, 1) * 1e3:.2f} ms/step, "
+      f"decode {dec_steps} steps, {(t1 - t_decode) / max(dec_steps, 1) * 1e3:.3f} ms/step, "
       f"{(produced - produced_at) / (t1 - t_decode):.0f} tok/s")

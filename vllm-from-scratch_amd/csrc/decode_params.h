@@ -48,6 +48,12 @@ struct DecodeParams {
   const void* v_new = nullptr;
   int64_t new_stride_seq = 0;
   int lds_new_off = 0;
+  // ... with rotary embedding applied on the way (non-null tables): q and the new K row arrive
+  // un-rotated and are rotated for position context - 1 (rotate-half form, tables [rope_len, D] in
+  // the cache's dtype) before use; the rotated K row is what the cache receives.
+  const void* rope_cos = nullptr;
+  const void* rope_sin = nullptr;
+  int rope_len = 0;
 };
 
 struct DecodePlan {

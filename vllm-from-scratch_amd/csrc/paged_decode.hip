@@ -84,6 +84,21 @@ struct DecodeLead {
   int qchunks, hgroups, nsplit, tps, bs_shift, max_blocks, max_ctx, hpw, gq;
 };
 
+// Rotate-half rotary embedding of one 16-byte piece: x = this lane's elements, y = the elements
+// D/2 away (the partner lane's), c / s = cos and sin of the piece's own dims.  Two products and a
+// sum, uncontracted, then one rounding by the caller's pack -- the arithmetic of
+// rope_kv_write_kernel (layer_ops.hip), so both paths give the same bits.
+template <int N>
+__device__ __forceinline__ void rope_combine(const float (&x)[N], const float (&y)[N], const float (&c)[N],
+                                             const float (&s)[N], bool low_half, float (&o)[N]) {
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    const float r = low_half ? -y[e] : y[e];
+    o[e] = x[e] * c[e] + r * s[e];
+  }
+}
+
 // APPEND (decode mode only): every sequence's newest K/V row arrives as an argument instead of
 // sitting in the cache already.  The wave whose token range holds the last position stores the
 // row there before it reads it, so the step's cache write needs no launch of its own.
@@ -202,6 +217,17 @@ paged_decode_kernel(const int32_t* a_bt, const int32_t* a_ctx, const void* a_q, 
     ctx_given = a_ctx[b];
     ctx = max(0, min(ctx_given, a_max_ctx));
   }
+  // Append mode with rotary embedding: cos / sin of the new token's position for this lane's dims
+  // (requested as soon as the length is known; used behind the table barrier)
+  u32x4 rope_c = {0u, 0u, 0u, 0u}, rope_s = {0u, 0u, 0u, 0u};
+  if constexpr (APPEND) {
+    if (p.rope_cos) {
+      const int pos = min(max(ctx_given - 1, 0), p.rope_len - 1);
+      const int64_t off = ((int64_t)pos * D + dg * EPL) * Tag::kBytes;
+      rope_c = load16<false>(static_cast<const char*>(p.rope_cos) + off);
+      rope_s = load16<false>(static_cast<const char*>(p.rope_sin) + off);
+    }
+  }
   // Splits past the context do nothing and the merge skips them; with the merge in this launch
   // split 0 always takes part, so that an empty sequence still gets its (zero) output row.
   const bool fused = !ROWS && p.counters != nullptr;
@@ -229,6 +255,33 @@ paged_decode_kernel(const int32_t* a_bt, const int32_t* a_ctx, const void* a_q, 
   // never use from standing in the way of the stream's own loads: a register whose load might
   // still be pending cannot be reused without waiting for everything issued after it.
   if constexpr (APPEND) asm("" : "+v"(new_k), "+v"(new_v));
+  if constexpr (APPEND) {
+    if (p.rope_cos) {
+      // q and the new K row arrive un-rotated: a lane holds EPL dims of a row, the dims D/2 away sit
+      // LPT/2 lanes further (same token group, and every token group holds the same pieces)
+      static_assert(LPT >= 2, "a row's halves are on different lanes");
+      float c[EPL], sn[EPL];
+      Tag::unpack(rope_c, c);
+      Tag::unpack(rope_s, sn);
+      const bool low_half = dg < LPT / 2;
+      auto rotated = [&](u32x4 raw) {
+        u32x4 other;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t w = raw[i];
+          other[i] = (uint32_t)__shfl_xor((int)w, LPT / 2);
+        }
+        float x[EPL], y[EPL], o[EPL];
+        Tag::unpack(raw, x);
+        Tag::unpack(other, y);
+        rope_combine<EPL>(x, y, c, sn, low_half, o);
+        return Tag::pack(o);
+      };
+#pragma unroll
+      for (int gi = 0; gi < G; ++gi) qraw[gi] = rotated(qraw[gi]);
+      new_k = rotated(new_k);
+    }
+  }
   DECODE_STAMP(1);
   // ROWS: the group's own context is shared out between the sub-range waves (early groups are short)
   const int len_w = ROWS ? (ctx + p.sub * TS - 1) / (p.sub * TS) * TS : p.tps / p.sub;
@@ -929,7 +982,8 @@ int paged_decode_impl(const char* what, void* out, const void* q, int64_t q_stri
                       int32_t num_blocks, int32_t max_context, int64_t kv_stride_block, int64_t kv_stride_head,
                       int64_t kv_stride_tok, float scale, int32_t dtype, void* workspace, size_t workspace_bytes,
                       void* stream, const void* k_new = nullptr, const void* v_new = nullptr,
-                      int64_t new_stride_seq = 0) {
+                      int64_t new_stride_seq = 0, const void* rope_cos = nullptr, const void* rope_sin = nullptr,
+                      int32_t rope_len = 0) {
   if (B == 0) return 0;
   if (!out || !q || !k_cache || !v_cache || !block_tables || !context_lens)
     return fail(MI355_EINVAL, "%s: null pointer argument", what);
@@ -1011,6 +1065,10 @@ int paged_decode_impl(const char* what, void* out, const void* q, int64_t q_stri
     // The matrix-core kernel reads finished caches, and a workgroup's LDS has its limit: there
     // the write goes first, as a launch of its own.
     if (pl.mfma || pl.lds_bytes + stash > 64 * 1024) {
+      // (with rotary embedding q is rotated inside the VALU kernel only: nothing has been launched yet)
+      if (rope_cos)
+        return fail(MI355_EUNSUPPORTED, "%s: this shape is served by the matrix-core kernel or fills the workgroup's "
+                                        "LDS; rotate with mi355_rope_kv_write and call mi355_paged_decode", what);
       AppendParams ap;
       ap.kc = static_cast<char*>(const_cast<void*>(k_cache));
       ap.vc = static_cast<char*>(const_cast<void*>(v_cache));
@@ -1040,6 +1098,9 @@ int paged_decode_impl(const char* what, void* out, const void* q, int64_t q_stri
       p.new_stride_seq = new_stride_seq;
       p.lds_new_off = (int)pl.lds_bytes;
       pl.lds_bytes += stash;
+      p.rope_cos = rope_cos;
+      p.rope_sin = rope_sin;
+      p.rope_len = rope_len;
     }
   }
   if (pl.mfma) return launch_gqa(p, pl, D, dtype, s);
@@ -1112,6 +1173,26 @@ extern "C" int mi355_paged_decode_append(void* out, const void* q, int64_t q_str
                            B, Hq, Hkv, D, block_size, max_blocks, num_blocks, max_context, kv_stride_block,
                            kv_stride_head, kv_stride_tok, scale, dtype, workspace, workspace_bytes, stream, k_new,
                            v_new, new_stride_seq);
+}
+
+extern "C" int mi355_paged_decode_append_rope(void* out, const void* q, int64_t q_stride_seq, const void* k_new,
+                                              const void* v_new, int64_t new_stride_seq, void* k_cache,
+                                              void* v_cache, const int32_t* block_tables,
+                                              const int32_t* context_lens, const void* cos_table,
+                                              const void* sin_table, int32_t table_len, int32_t B, int32_t Hq,
+                                              int32_t Hkv, int32_t D, int32_t block_size, int32_t max_blocks,
+                                              int32_t num_blocks, int32_t max_context, int64_t kv_stride_block,
+                                              int64_t kv_stride_head, int64_t kv_stride_tok, float scale,
+                                              int32_t dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  if (B == 0) return 0;
+  if (!k_new || !v_new || !cos_table || !sin_table)
+    return fail(MI355_EINVAL, "paged_decode_append_rope: null pointer argument");
+  if (table_len <= 0 || (((uintptr_t)cos_table | (uintptr_t)sin_table) & 15))
+    return fail(MI355_EINVAL, "paged_decode_append_rope: cos / sin tables must be [table_len, D], 16-byte aligned");
+  return paged_decode_impl("paged_decode_append_rope", out, q, q_stride_seq, k_cache, v_cache, block_tables,
+                           context_lens, B, Hq, Hkv, D, block_size, max_blocks, num_blocks, max_context,
+                           kv_stride_block, kv_stride_head, kv_stride_tok, scale, dtype, workspace, workspace_bytes,
+                           stream, k_new, v_new, new_stride_seq, cos_table, sin_table, table_len);
 }
 
 extern "C" int mi355_paged_decode_static(void* out, const void* q, int64_t q_stride_seq, const void* k_cache,

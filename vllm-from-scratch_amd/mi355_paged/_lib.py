@@ -26,6 +26,11 @@ SIGNATURES = {
         c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
         c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
         c_int64, c_int64, c_int64, c_float, c_int32, c_void_p, c_size_t, c_void_p]),
+    'mi355_paged_decode_append_rope': (c_int, [
+        c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+        c_void_p, c_void_p, c_int32,
+        c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+        c_int64, c_int64, c_int64, c_float, c_int32, c_void_p, c_size_t, c_void_p]),
     'mi355_paged_decode_static': (c_int, [
         c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
         c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,

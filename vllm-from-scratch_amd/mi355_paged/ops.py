@@ -201,11 +201,16 @@ def paged_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
 def paged_decode_append(q: torch.Tensor, k_new: torch.Tensor, v_new: torch.Tensor, k_cache: torch.Tensor,
                         v_cache: torch.Tensor, block_tables: torch.Tensor, context_lens: torch.Tensor,
                         max_context: int, layout: str = 'NHSD', scale: Optional[float] = None,
-                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                        out: Optional[torch.Tensor] = None,
+                        rope: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
     """One decode step of an attention layer: k_new / v_new [B, Hkv, D] go to position
     context_lens[b] - 1 of every sequence's cache, then q attends to the context_lens[b] cached
     rows.  Same result (output and caches) as kv_write_slots at those slots followed by
-    paged_decode; where the VALU decode kernel runs, in one launch."""
+    paged_decode; where the VALU decode kernel runs, in one launch.
+    rope = (cos_table, sin_table), each [table_len, D] in the cache's dtype: q and k_new are given
+    UN-rotated and are rotated for position context_lens[b] - 1 inside the launch (q itself is left
+    as it is); raises Mi355Error (status MI355_EUNSUPPORTED, nothing launched) for the shapes whose
+    cache write is a launch of its own -- see paged_decode_append_rope_serves."""
     dev = require_device(q, k_new, v_new, k_cache, v_cache, block_tables, context_lens)
     lib = _lib.load()
     if q.dim() != 3 or q.stride(2) != 1 or q.stride(1) != q.shape[2]:
@@ -245,14 +250,39 @@ def paged_decode_append(q: torch.Tensor, k_new: torch.Tensor, v_new: torch.Tenso
         need = lib.mi355_paged_decode_workspace_bytes(B, Hq, g['heads'], D, g['block_size'],
                                                       max_context, code)
         ws, ws_bytes = _workspace(dev, need, stream)
-        rc = lib.mi355_paged_decode_append(
-            out.data_ptr(), q.data_ptr(), _stride(q, 0), k_new.data_ptr(), v_new.data_ptr(), _stride(k_new, 0),
-            k_cache.data_ptr(), v_cache.data_ptr(), block_tables.data_ptr(), context_lens.data_ptr(),
-            B, Hq, g['heads'], D, g['block_size'], block_tables.shape[1], g['num_blocks'], max_context,
-            g['s_block'], g['s_head'], g['s_tok'], float(scale), code,
-            ws.data_ptr() if ws is not None else None, ws_bytes, stream)
-    _lib.check(rc, 'mi355_paged_decode_append')
+        if rope is None:
+            rc = lib.mi355_paged_decode_append(
+                out.data_ptr(), q.data_ptr(), _stride(q, 0), k_new.data_ptr(), v_new.data_ptr(), _stride(k_new, 0),
+                k_cache.data_ptr(), v_cache.data_ptr(), block_tables.data_ptr(), context_lens.data_ptr(),
+                B, Hq, g['heads'], D, g['block_size'], block_tables.shape[1], g['num_blocks'], max_context,
+                g['s_block'], g['s_head'], g['s_tok'], float(scale), code,
+                ws.data_ptr() if ws is not None else None, ws_bytes, stream)
+        else:
+            cos_t, sin_t = rope
+            if not (cos_t.dtype == sin_t.dtype == q.dtype) or cos_t.shape != sin_t.shape or cos_t.dim() != 2 \
+                    or cos_t.shape[1] != D or not cos_t.is_contiguous() or not sin_t.is_contiguous() \
+                    or cos_t.device != dev or sin_t.device != dev:
+                raise ValueError("rope tables must be contiguous [table_len, head_dim] tensors of q's dtype and device")
+            rc = lib.mi355_paged_decode_append_rope(
+                out.data_ptr(), q.data_ptr(), _stride(q, 0), k_new.data_ptr(), v_new.data_ptr(), _stride(k_new, 0),
+                k_cache.data_ptr(), v_cache.data_ptr(), block_tables.data_ptr(), context_lens.data_ptr(),
+                cos_t.data_ptr(), sin_t.data_ptr(), cos_t.shape[0],
+                B, Hq, g['heads'], D, g['block_size'], block_tables.shape[1], g['num_blocks'], max_context,
+                g['s_block'], g['s_head'], g['s_tok'], float(scale), code,
+                ws.data_ptr() if ws is not None else None, ws_bytes, stream)
+    _lib.check(rc, 'mi355_paged_decode_append' if rope is None else 'mi355_paged_decode_append_rope')
     return out
+
+
+def paged_decode_append_rope_serves(dtype: torch.dtype, heads_q: int, heads_kv: int, head_dim: int) -> bool:
+    """Whether paged_decode_append(rope=...) runs as one launch for this geometry: everything the VALU
+    decode kernel serves, i.e. not the grouped-query shapes of the matrix-core kernel (16-bit,
+    head_dim 64 / 128, four or more query heads per kv head).  (A plan whose LDS is full is refused
+    at the call; that takes contexts beyond what a workgroup stages.)"""
+    if head_dim not in (16, 32, 64, 128, 256) or heads_kv <= 0 or heads_q % heads_kv:
+        return False
+    grouped = heads_q // heads_kv >= 4 and dtype in (torch.bfloat16, torch.float16) and head_dim in (64, 128)
+    return not grouped
 
 
 def kv_write_slots(k_cache: torch.Tensor, v_cache: torch.Tensor, k: torch.Tensor, v: torch.Tensor,

@@ -577,6 +577,10 @@ class AttnPlan:
     append_meta: Optional[torch.Tensor] = None        # int32 [3, nseg]: first token row, length, first position
     max_append_len: int = 0
     max_append_context: int = 0
+    # every token of the step is the one new token of a request past its prompt (row r attends to
+    # paged_context[r] = its position + 1 cached rows): RoPE, cache write and attention of a layer
+    # can then be ONE launch (ops.paged_decode_append with rope tables)
+    pure_decode: bool = False
 
 
 def build_attn_plan(positions: Sequence[int], seq_lens: Sequence[int], is_prefill: Sequence[bool],
@@ -604,8 +608,10 @@ def build_attn_plan(positions: Sequence[int], seq_lens: Sequence[int], is_prefil
     use_rows = device_tables is not None and table_rows is not None and not reference_compat
     compat = reference_compat or (block_tables is None and not use_rows)
     tok = 0
+    pure_decode = not compat
     for r, (n, prefill) in enumerate(zip(seq_lens, is_prefill)):
         n_q = n if prefill else 1
+        pure_decode = pure_decode and not prefill
         start = int(positions[tok]) if n > 0 else 0
         if prefill and (compat or start == 0):
             causal_tok.extend(range(tok, tok + n_q))
@@ -647,7 +653,8 @@ def build_attn_plan(positions: Sequence[int], seq_lens: Sequence[int], is_prefil
 
     plan = AttnPlan(total_tokens=total, causal_index=None, cu_seqlens=None, causal_tokens=len(causal_tok),
                     max_causal_len=max_len, paged_index=None, paged_tables=None, paged_context=None,
-                    paged_rows=len(paged_tok), max_context=max(paged_ctx) if paged_ctx else 0)
+                    paged_rows=len(paged_tok), max_context=max(paged_ctx) if paged_ctx else 0,
+                    pure_decode=pure_decode and len(paged_tok) == total and total > 0)
     if causal_tok:
         plan.causal_index = idx(causal_tok)
         plan.cu_seqlens = _upload(cu, torch.int32, device)
@@ -813,6 +820,7 @@ class SelfAttention(nn.Module):
         self.qkv = nn.Linear(hidden_size, 3 * num_heads * head_dim, bias=False)
         self.out_proj = nn.Linear(num_heads * head_dim, hidden_size, bias=False)
         self.rope = RotaryEmbedding(head_dim)
+        self.fuse_decode_step = True     # pure-decode steps: RoPE + cache write + attention in one launch
 
     def forward(self, x, positions, kv_cache, slot_mapping, seq_lens, is_prefill, plan: Optional[AttnPlan] = None):
         T, H, D = x.shape[0], self.num_heads, self.head_dim
@@ -823,8 +831,14 @@ class SelfAttention(nn.Module):
         k_cache, v_cache = kv_cache
         cos_t, sin_t = self.rope.cos_cached, self.rope.sin_cached
         per32 = 32 // x.element_size()      # the fused kernel moves two 16-byte pieces per half row
-        if (_kernel_rows(qkv, cos_t, sin_t) and k_cache.is_cuda and k_cache.dtype == x.dtype and D % per32 == 0
-                and positions.dtype == torch.int64 and slot_mapping.dtype == torch.int64):
+        fusable = (_kernel_rows(qkv, cos_t, sin_t) and k_cache.is_cuda and k_cache.dtype == x.dtype and D % per32 == 0
+                   and positions.dtype == torch.int64 and slot_mapping.dtype == torch.int64)
+        if fusable and plan.pure_decode and self.fuse_decode_step and ops.paged_decode_append_rope_serves(x.dtype, H, H, D):
+            # a step of decode tokens only: RoPE of q and k, the cache write and attention in ONE launch
+            # (the new token of row r sits at position paged_context[r] - 1, where its K/V row belongs)
+            attn = ops.paged_decode_append(q, k, v, k_cache, v_cache, plan.paged_tables, plan.paged_context,
+                                           plan.max_context, layout='NSHD', scale=self.scale, rope=(cos_t, sin_t))
+        elif fusable:
             # RoPE on q and k in place inside the projection output + cache write, one launch
             ops.rope_kv_write(q, k, v, cos_t, sin_t, positions, slot_mapping, k_cache, v_cache, layout='NSHD')
             attn = paged_attention_step(q, k, v, k_cache, v_cache, slot_mapping, plan, self.scale, kv_written=True)
@@ -1029,7 +1043,7 @@ class DecodeStepGraph:
                                                               self.prev_ids)
         plan = AttnPlan(total_tokens=self.rows, causal_index=None, cu_seqlens=None, causal_tokens=0,
                         max_causal_len=0, paged_index=None, paged_tables=tables, paged_context=ctx,
-                        paged_rows=self.rows, max_context=self.max_context)
+                        paged_rows=self.rows, max_context=self.max_context, pure_decode=True)
         return self.model.forward_planned(tok, pos, slots, plan)
 
     def run(self, tokens: Sequence[int], positions: Sequence[int], rows: Sequence[int],
@@ -1221,7 +1235,11 @@ class MiniVLLM:
                  enable_chunked_prefill: bool = True, device: str = 'cpu',
                  reference_compat: bool = False, dtype: Optional[torch.dtype] = None,
                  decode_graphs: bool = True, enable_prefix_caching: bool = False,
-                 decode_lookahead: bool = True, pipeline_steps: bool = True):
+                 decode_lookahead: bool = True, pipeline_steps: bool = True, fused_decode_step: bool = True):
+        """The first eleven arguments are the reference's (05_mini_vllm/mini_vllm.py:649-662); the
+        rest select this implementation's execution modes, every one of which gives every request
+        the same tokens.  fused_decode_step: in a step of decode tokens only, RoPE, the cache write
+        and attention of a layer are one launch (False: RoPE + cache write, then attention)."""
         self.device = torch.device(device)
         self.reference_compat = reference_compat
         # replay pure-decode steps as HIP graphs (device-resident engines only)
@@ -1255,6 +1273,8 @@ class MiniVLLM:
                                      num_kv_blocks=num_kv_blocks, block_size=block_size).to(self.device)
         if dtype is not None:
             self.model = self.model.to(dtype)
+        for layer in self.model.layers:
+            layer.attn.fuse_decode_step = fused_decode_step
         self.sampler = Sampler()
         self._req_counter = 0
         self._device_tables: Optional[DeviceBlockTables] = None   # created on first use (needs a HIP device)
