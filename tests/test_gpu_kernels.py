@@ -1127,6 +1127,61 @@ def test_sampling_top_k_on_streamed_rows_from_the_candidate_list(ops, device):
         assert np.all(np.abs(counts[b][kept_sets[b]] - expect) < 5.5 * sigma), f"row {b}"
 
 
+@pytest.mark.parametrize('vocab', [900, 12000, 32000])     # the three register-resident kernel shapes
+def test_sampling_top_k_on_register_rows_from_the_candidate_list(ops, device, vocab):
+    """Rows that live in registers take cut, tie rule, kept mass and draw of a top-k limit (with or
+    without a nucleus cut) from a short list of the candidates at or above a lower bound of the k-th
+    largest weight.  Rows whose candidates fit (distinct values; 300 copies of the largest value, of
+    which the lowest indices stay) and rows that fall back to the walk over the row (more copies
+    than the list holds; a constant row; fewer positive weights than k) keep the oracle's set, the
+    kept probabilities are the oracle's, the same seed gives the same tokens, and the draws -- with
+    no distribution asked for, the production form -- follow the kept distribution."""
+    rng = np.random.default_rng(vocab)
+    base = (rng.standard_normal(vocab) * 2).astype(np.float32)
+    rows, top_ps, top_ks = [base.copy(), base.copy(), base.copy()], [1.0, 0.6, 1.0], [50, 50, 128 if vocab > 1024 else 30]
+    for copies in (300, 700):
+        x = base.copy()
+        x[rng.choice(vocab, size=copies, replace=False)] = 9.0
+        rows.append(x); top_ps.append(1.0); top_ks.append(20)
+    rows.append(np.full(vocab, 0.25, dtype=np.float32)); top_ps.append(1.0); top_ks.append(7)
+    peaked = np.full(vocab, -200.0, dtype=np.float32)      # five positive weights, the rest underflow
+    peaked[[3, 17, 400, 401, vocab - 1]] = [5.0, 4.0, 4.0, 3.0, 1.0]
+    rows.append(peaked); top_ps.append(1.0); top_ks.append(12)
+    nrow = len(rows)
+    logits = torch.from_numpy(np.stack(rows)).to(device)
+    temps = torch.ones(nrow, device=device)
+    tp = torch.tensor(top_ps, device=device)
+    tk = torch.tensor(top_ks, dtype=torch.int32, device=device)
+    ids, probs = ops.sample_topk_topp(logits, temps, tp, tk, seed=9, return_probs=True)
+    probs = probs.cpu().numpy()
+    kept_sets = []
+    for b in range(nrow):
+        want, kept = orc.nucleus_probs(rows[b], 1.0, top_ps[b], top_ks[b])
+        got_kept = probs[b] > 0
+        positive = want > 0
+        assert np.array_equal(got_kept, kept & positive), f"row {b}: {got_kept.sum()} kept, {int(kept.sum())} expected"
+        np.testing.assert_allclose(probs[b], want, rtol=2e-5, atol=1e-7)
+        assert got_kept[int(ids[b])]
+        kept_sets.append(np.nonzero(got_kept)[0])
+    plain = ops.sample_topk_topp(logits, temps, tp, tk, seed=9)
+    assert torch.equal(ids, plain)                          # asking for the distribution does not change the draw
+    reps, nseeds = 64, 40
+    tiled = logits.repeat_interleave(reps, dim=0)
+    t_temps = torch.ones(tiled.shape[0], device=device)
+    counts = np.zeros((nrow, vocab), dtype=np.int64)
+    for seed in range(nseeds):
+        got = ops.sample_topk_topp(tiled, t_temps, tp.repeat_interleave(reps), tk.repeat_interleave(reps),
+                                   seed=500 + seed).cpu().numpy().reshape(nrow, reps)
+        for b in range(nrow):
+            np.add.at(counts[b], got[b], 1)
+    n = nseeds * reps
+    for b in range(nrow):
+        assert counts[b].sum() == n and counts[b][kept_sets[b]].sum() == n, f"row {b}: a token outside the kept set"
+        expect = probs[b][kept_sets[b]].astype(np.float64) * n
+        sigma = np.sqrt(np.maximum(expect * (1 - expect / n), 1.0))
+        assert np.all(np.abs(counts[b][kept_sets[b]] - expect) < 5.5 * sigma), f"row {b}"
+
+
 @pytest.mark.parametrize('vocab', [5000, 20000, 32000, 50000, 128256])   # (the last two: rows beyond the registers)
 def test_sampling_nucleus_from_flat_to_peaked_rows(ops, device, vocab):
     """Kept sets against the oracle for nucleus cuts from 0.3 to 0.999 on rows from flat to very

@@ -20,8 +20,9 @@ temp = torch.ones(B, device=dev)
 NAMES = {0: 'start', 1: 'loaded + max', 2: 'exp + sum', 3: 'L0 bins zeroed', 4: 'L0 tallied', 5: 'L0 scanned', 6: 'L0 cut known',
          7: 'L0 list built', 8: 'L1 zeroed', 9: 'L1 tallied', 10: 'L1 scanned', 11: 'L1 cut', 12: 'L1 end', 13: 'L2 zeroed',
          14: 'L2 tallied', 15: 'L2 scanned', 16: 'L2 cut', 17: 'L2 end', 18: 'search done', 19: 'ties done', 20: 'draw start',
-         21: 'draw scanned', 22: 'picker known', 23: 'walk'}
-for label, tp, tk in (('top_p=0.9', 0.9, 0), ('top_k=50', 1.0, 50), ('top_p=0.5', 0.5, 0)):
+         21: 'draw scanned', 22: 'picker known', 23: 'walk',
+         24: 'list: bound', 25: 'list: collected', 26: 'list: ordered', 27: 'list: picked'}
+for label, tp, tk in (('top_k=50', 1.0, 50), ('top_p=0.9', 0.9, 0), ('top_p=0.5', 0.5, 0)):
     top_p = torch.full((B,), tp, device=dev)
     top_k = torch.full((B,), tk, dtype=torch.int32, device=dev)
     for _ in range(3):
@@ -30,7 +31,8 @@ for label, tp, tk in (('top_p=0.9', 0.9, 0), ('top_k=50', 1.0, 50), ('top_p=0.5'
     st = probs.view(torch.int64).view(-1)[:B * 32].view(B, 32).cpu().numpy()
     print(label)
     prev = 0
-    for n in sorted(NAMES):
+    order = [0, 1, 2, 24, 25, 26, 27] if np.median(st[:, 27] - st[:, 0]) > 0 and tk else sorted(n for n in NAMES if n < 24)
+    for n in order:
         at = np.median(st[:, n] - st[:, 0])
         if n > 0 and not (0 < at < 5e5):       # a stamp this mode never wrote (the buffer is not cleared)
             continue

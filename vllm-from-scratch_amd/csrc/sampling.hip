@@ -67,6 +67,18 @@ __device__ __forceinline__ float wave_prefix_sum(float v) {
   v += dpp_move_f<0x143, 0xc>(v);
   return v;
 }
+__device__ __forceinline__ int wave_prefix_max_int(int v) {      // inclusive prefix maximum over the lanes, v >= 0
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));
+  return v;
+}
+__device__ __forceinline__ float lane_shift_up(float v) {         // lane l gets lane l - 1's value (lane 0: its own)
+  return __shfl_up(v, 1);
+}
 __device__ __forceinline__ unsigned long long lane_u64(unsigned long long v, int l) {   // l wave-uniform
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
   const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
@@ -292,6 +304,19 @@ __device__ __forceinline__ float exp_nonpos(float d) {
 #endif
 }
 
+// A probability as the cut search tallies it: count 1 in the bits from 41 up, the value in units of
+// 2^-40 below them.  Sums of such words are exact and do not depend on the order of addition.
+__device__ __forceinline__ unsigned long long packed_prob(float q) {
+  return (1ull << 41) + (unsigned long long)(q * 1099511627776.0f);
+}
+// mass field (41 bits, units of 2^-40) -> float, correctly rounded: the upper 24 bits and the
+// lower 17 are each exact as floats and their sum is rounded once -- what the generic 64-bit
+// conversion returns, in a third of its instructions.
+__device__ __forceinline__ float packed_mass(unsigned long long packed) {
+  const unsigned long long m = packed & ((1ull << 41) - 1);
+  return __builtin_fmaf((float)(uint32_t)(m >> 17), 131072.0f, (float)((uint32_t)m & 0x1FFFFu)) * 0x1p-40f;
+}
+
 // VPT > 0: the row's probabilities live in registers (VPT per thread).
 // VPT == 0: they are recomputed from the logits on every pass (any vocab size).
 // VEC: the row is read in 16-byte pieces (row base and stride 16-byte aligned, vocab a multiple of
@@ -319,6 +344,17 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
   __shared__ float s_cand_x[kCandCap], s_cand_sx[kCandCap];
   __shared__ int s_cand_i[kCandCap], s_cand_si[kCandCap];
   __shared__ int s_cand_n;
+  // register-resident rows under a top-k limit: the candidates at or above a lower bound of the
+  // k-th largest weight (weight and index as collected, then probability), and the k largest of
+  // them in descending order (probability, index, rank of the first copy of the value, and what
+  // lies above each rank as a packed count | mass)
+  constexpr int kTopCap = VPT == 0 ? 4 : (NT < 512 ? NT : 512);
+  constexpr int kTopK = 128;
+  __shared__ __attribute__((aligned(16))) unsigned long long s_top_key[kTopCap + 2];
+  __shared__ int s_top_rank[kTopCap];
+  __shared__ float s_top_bound[kMaxWaves];
+  __shared__ unsigned long long s_srt_key[kTopK];
+  __shared__ unsigned long long s_srt_above[kTopK + 1];
   constexpr int kTieCap = 64;
   __shared__ int s_tie_i[kTieCap];
   __shared__ int s_tie_n;
@@ -495,6 +531,164 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
     z = block_reduce(z, addf, xch, slot);
     const float inv_z = 1.0f / z;
     STAMP(2);
+    // Under a top-k limit of up to 128 the whole rest of the row's work -- cut, tie rule, kept
+    // mass, draw -- is done on a short list.  A lower bound of the k-th largest weight comes from
+    // the threads' largest weights (every wave takes the k'-th largest of its lanes' largest,
+    // k' = ceil(k / waves): at least k' different elements are >= it, so the smallest of the waves'
+    // values has at least k elements at or above it); the elements at or above it -- a hundred or
+    // two of 32000 -- go to LDS with their indices, only they are normalised (by the expression
+    // every other path uses, so probabilities are the same bits), each finds its place in the
+    // descending order (ties: lower index first, the stable sort of the reference,
+    // 05_mini_vllm/mini_vllm.py:620) by counting the candidates ahead of it, and the first k in
+    // that order are everything the cut and the draw need: no histogram over the row, no
+    // normalisation of the row, no pass for the kept mass.  What lies above a value is summed as
+    // the histogram bins would sum it (packed_prob: exact, order-free), so the kept set is the
+    // one the bin search finds.  A row whose candidates do not fit (long constant stretches, fewer
+    // than k positive weights) takes the general path below.
+    {
+      const int nwv = nt >> 6;
+      const int per_wave = tk > 0 ? (tk + nwv - 1) / nwv : 0;
+      if (per_wave >= 1 && per_wave <= 8) {              // (the same for the whole row)
+        float top = 0.f;                                 // weights are >= 0; absent elements weigh 0
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) top = fmaxf(top, pr[j]);
+        float kth = 0.f;
+        for (int r = 0; r < per_wave; ++r) {
+          kth = wave_reduce(top, fmaxop);
+          const unsigned long long holders = __ballot(top == kth);
+          if (lane == __ffsll((long long)holders) - 1) top = -1.0f;   // one lane gives its value up per round
+        }
+        if (lane == 0) s_top_bound[wave] = kth;
+        if (tid == 0) s_cand_n = 0;
+        if (tid < kTopCap) {
+          s_top_rank[tid] = 0;
+          s_top_key[tid] = 0ull;                         // (entries past the list: behind every candidate)
+        }
+        __syncthreads();
+        STAMP(24);
+        float lowest = s_top_bound[0];
+#pragma unroll
+        for (int w = 1; w < kMaxWaves; ++w) lowest = fminf(lowest, s_top_bound[w < nwv ? w : 0]);
+        // Candidates: a wave counts its own (the comparison's lane mask is the ballot: one vector
+        // instruction and a scalar population count per round), reserves its stretch of the list with
+        // one counter update, and goes over the row once more to write them, most rounds finding none.
+        // A candidate is kept as one 64-bit key, probability bits above the complemented index: a
+        // larger key comes first in the order (probabilities are positive floats, whose bit patterns
+        // order as the values do; of two equal ones the lower index wins).
+        int wave_n = 0;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) wave_n += __popcll(__ballot(pr[j] >= lowest));
+        if (lowest <= 0.f) wave_n = kTopCap + 1;         // fewer than k positive weights: no list
+        int at = 0;
+        if (lane == 0) at = atomicAdd(&s_cand_n, wave_n);
+        at = __builtin_amdgcn_readfirstlane(at);
+        if (wave_n > 0 && at + wave_n <= kTopCap) {
+#pragma unroll
+          for (int j = 0; j < VPT; ++j) {
+            const bool hit = pr[j] >= lowest;
+            const unsigned long long hits = __ballot(hit);
+            if (hits) {                                  // (wave-uniform; one round in four finds anything)
+              // (the empty statement keeps the division and the lane count inside this branch: hoisted
+              // out, as the compiler otherwise does, they run for all 32 elements of every thread)
+              float e = pr[j];
+              asm volatile("" : "+v"(e));
+              const int pos = at + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32),
+                                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u));
+              if (hit)
+                s_top_key[pos] = ((unsigned long long)__builtin_bit_cast(uint32_t, div_shared(e, z, inv_z)) << 32) |
+                                 (uint32_t)~eidx(j);
+              at += __popcll(hits);
+            }
+          }
+        }
+        __syncthreads();
+        const int n = s_cand_n;
+        if (n <= kTopCap) {
+          STAMP(25);
+          // Place of every candidate in the descending order = the number of larger keys.  The
+          // threads of the workgroup share the comparisons: thread = (candidate, slice of the list).
+          const int n2 = (n + 1) & ~1;
+          const int parts = nt / n;                      // >= 1: 1 <= n <= kTopCap <= nt
+          const int part = tid / n, c = tid - part * n;
+          const int per_part = (((n2 >> 1) + parts - 1) / parts) << 1;
+          if (part < parts) {
+            const unsigned long long key = s_top_key[c];
+            const int m0 = part * per_part, m1 = min(m0 + per_part, n2);
+            int ahead = 0;
+            for (int m = m0; m < m1; m += 2) {           // two candidates per read
+              const ulonglong2 km = *reinterpret_cast<const ulonglong2*>(&s_top_key[m]);
+              ahead += (km.x > key) + (km.y > key);
+            }
+            if (ahead) atomicAdd(&s_top_rank[c], ahead);
+          }
+#ifndef SAMPLER_TIMING
+          if (p.out_probs) {                             // every entry is 0 except the kept ones, written below
+            float* dst = p.out_probs + (int64_t)b * vocab;
+#pragma unroll
+            for (int j = 0; j < VPT; ++j)
+              if (eidx(j) < vocab) dst[eidx(j)] = 0.f;
+          }
+#endif
+          __syncthreads();
+          if (tid < n) {
+            const int rank = s_top_rank[tid];
+            if (rank < kTopK) s_srt_key[rank] = s_top_key[tid];
+          }
+          __syncthreads();
+          STAMP(26);
+          if (wave != 0) return;
+          // Wave 0 alone takes it from here, two ranks per lane (rank = lane, lane + 64), the first
+          // nk = min(k, n) of the order.  first = rank of the first copy of the entry's value (equal
+          // values are neighbours in the order); above[r] = packed (count | mass) of ranks 0 .. r - 1.
+          const int nk = min(min(tk, n), kTopK);
+          const bool live0 = lane < nk, live1 = lane + kWave < nk;
+          const unsigned long long k0 = live0 ? s_srt_key[lane] : 0ull, k1 = live1 ? s_srt_key[lane + kWave] : 0ull;
+          const float q0 = __builtin_bit_cast(float, (uint32_t)(k0 >> 32)), q1 = __builtin_bit_cast(float, (uint32_t)(k1 >> 32));
+          const int i0 = (int)~(uint32_t)k0, i1 = (int)~(uint32_t)k1;
+          // a value starts where it differs from the entry before it; the start's rank is carried forward
+          const float before0 = lane > 0 ? lane_shift_up(q0) : -1.0f;
+          const float before1 = lane > 0 ? lane_shift_up(q1) : lane_f(q0, kWave - 1);
+          const int f0 = wave_prefix_max_int(q0 != before0 ? lane : 0);
+          const int f1 = max(wave_prefix_max_int(q1 != before1 ? lane + kWave : 0), __builtin_amdgcn_readlane(f0, kWave - 1));
+          const unsigned long long in0 = wave_prefix_sum_u64(live0 ? packed_prob(q0) : 0ull);
+          const unsigned long long in1 = wave_prefix_sum_u64(live1 ? packed_prob(q1) : 0ull) + lane_u64(in0, kWave - 1);
+          if (lane == 0) s_srt_above[0] = 0ull;
+          s_srt_above[lane + 1] = in0;
+          s_srt_above[lane + 1 + kWave] = in1;
+          __builtin_amdgcn_wave_barrier();               // (written and read by this wave only)
+          // copy j of a value is kept iff (mass above the value) + j * value < top_p and its rank < k;
+          // the top token always stays (05_mini_vllm/mini_vllm.py:624)
+          const bool use_p = tp < 1.0f;
+          const float a0 = packed_mass(s_srt_above[f0]), a1 = packed_mass(s_srt_above[f1]);
+          const bool kept0 = live0 && (lane == 0 || !use_p || a0 + (float)(lane - f0) * q0 < tp);
+          const bool kept1 = live1 && (!use_p || a1 + (float)(lane + kWave - f1) * q1 < tp);
+          // kept entries are a prefix of the order: its length, and its mass as the general path
+          // forms it (mass above the last kept value + its kept copies times the value)
+          const int kept_n = __popcll(__ballot(kept0)) + __popcll(__ballot(kept1));   // >= 1
+          const int last = kept_n - 1;
+          const float m0v = a0 + (float)(lane - f0 + 1) * q0, m1v = a1 + (float)(lane + kWave - f1 + 1) * q1;
+          const float kept_mass_l = last < kWave ? lane_f(m0v, last) : lane_f(m1v, last - kWave);
+          const float target = s_uniform * kept_mass_l;
+          const float run0 = wave_prefix_sum(lane < kept_n ? q0 : 0.f);
+          const float run1 = wave_prefix_sum(lane + kWave < kept_n ? q1 : 0.f) + lane_f(run0, kWave - 1);
+          const unsigned long long hit0 = __ballot(lane < kept_n && run0 > target);
+          const unsigned long long hit1 = __ballot(lane + kWave < kept_n && run1 > target);
+          // (rounding may push the target past the total: the last kept entry takes it)
+          const int pick = hit0 ? __ffsll((long long)hit0) - 1 : hit1 ? kWave + __ffsll((long long)hit1) - 1 : last;
+          const int pick_i = pick < kWave ? __builtin_amdgcn_readlane(i0, pick) : __builtin_amdgcn_readlane(i1, pick - kWave);
+          if (lane == 0) p.out[b] = pick_i;
+          STAMP(27);
+#ifndef SAMPLER_TIMING
+          if (p.out_probs) {
+            float* dst = p.out_probs + (int64_t)b * vocab;
+            if (lane < kept_n) dst[i0] = q0 / kept_mass_l;
+            if (lane + kWave < kept_n) dst[i1] = q1 / kept_mass_l;
+          }
+#endif
+          return;
+        }
+      }
+    }
 #pragma unroll
     for (int j = 0; j < VPT; ++j) pr[j] = (eidx(j) < vocab) ? div_shared(pr[j], z, inv_z) : -1.0f;   // -1 marks "no element"
   } else {
@@ -675,14 +869,7 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
     // rounds to 1.0f, and `mass < 1.0f` would drop them from a row that only has a top-k limit.
     const bool use_p = tp < 1.0f;
     auto ok = [&](float mass, int count) { return (!use_p || mass < tp) && count < kk; };
-    constexpr unsigned long long kMassMask = (1ull << 41) - 1;
-    // mass field (41 bits, units of 2^-40) -> float, correctly rounded: the upper 24 bits and the
-    // lower 17 are each exact as floats and their sum is rounded once -- what the generic 64-bit
-    // conversion returns, in a third of its instructions.
-    auto mass_of = [&](unsigned long long packed) {
-      const unsigned long long m = packed & kMassMask;
-      return __builtin_fmaf((float)(uint32_t)(m >> 17), 131072.0f, (float)((uint32_t)m & 0x1FFFFu)) * 0x1p-40f;
-    };
+    auto mass_of = [&](unsigned long long packed) { return packed_mass(packed); };
     constexpr int kLevelShift[3] = {kHistShift, 8, 0};
     constexpr int kLevelBits[3] = {11, 11, 8};        // level 0: bit 31 is the sign (0), keys < kHistBins
     static_assert(kHistShift == 19 && kHistBins == 2048, "the three fields must tile the 32 bits");
