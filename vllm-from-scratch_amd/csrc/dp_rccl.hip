@@ -151,7 +151,17 @@ extern "C" int mi355_dp_exchange_create(void* comm, void** exchange_out) {
   Exchange* x = new Exchange;
   x->comm = comm;
   hipError_t e = hipGetDevice(&x->device);
-  if (!e) e = hipStreamCreateWithFlags(&x->side, hipStreamNonBlocking);
+  if (!e) {
+    // A stream created WITH A PRIORITY (lowest: its kernels wait for ids and move a few hundred
+    // bytes) gets a hardware queue of its own class.  On a plain second stream a resident watcher --
+    // or a blocked barrier packet -- slowed the compute stream's workgroup dispatch: a decode launch
+    // of 2048 workgroups ran 3 us longer (163 -> 166 us), one of 256 long workgroups did not; with
+    // the priority stream the step costs 0.3-0.5 us more than with no exchange at all, at either end
+    // of the priority range.
+    int least = 0, greatest = 0;
+    e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (!e) e = hipStreamCreateWithPriority(&x->side, hipStreamNonBlocking, least);
+  }
   if (!e) e = hipHostMalloc(reinterpret_cast<void**>(&x->gave_up), sizeof(int), hipHostMallocMapped);
   if (!e) *x->gave_up = 0;
   for (int i = 0; i < kExchangeSlots && !e; ++i) e = hipEventCreateWithFlags(&x->done[i], hipEventDisableTiming);
