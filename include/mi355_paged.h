@@ -294,7 +294,35 @@ int mi355_mla_decode(float* out, const void* q, int64_t q_stride_row,
                      int32_t rows, int32_t H, int32_t R, int32_t P, int32_t max_context,
                      float scale, int32_t dtype, void* workspace, size_t workspace_bytes, void* stream);
 
-/* Scratch bytes mi355_mla_decode needs for this shape. */
+/*
+ * mi355_mla_decode over a BLOCK cache: the latent rows of a sequence live in fixed-size blocks of a
+ * shared pool, named by the sequence's block table, exactly as the K/V rows of
+ * mi355_paged_decode do -- so that latent caches can use the same block allocator, block tables
+ * and prefix sharing.  The reference keeps dense per-sequence tensors (MLAKVCache,
+ * 04_mla/mini_mla.py:79-132, and the past_c_kv / past_k_rope arguments of forward, :203-232); the
+ * attention computed is the same (:234-299), and a dense cache copied into any set of blocks
+ * gives the dense call's result bit for bit.
+ *   c_kv, k_rope  row `r` of block `blk`: blk * *_stride_block + r * *_stride_tok.  A pool
+ *                 [num_blocks, block_size, R + P] holding [c_kv | k_rope] per row is c_kv = pool,
+ *                 k_rope = pool + R, both with strides (block_size * (R + P), R + P).
+ *   block_tables  [sequences, max_blocks] int32; row_seq[row] (or row) selects the table row;
+ *                 token t sits in block block_tables[s][t / block_size] (ids clamped to
+ *                 [0, num_blocks)), row t % block_size.  block_size must be a power of two.
+ *   context_lens are clamped to min(max_context, max_blocks * block_size).
+ * Everything else (q, out, tables, workspace from mi355_mla_decode_workspace_bytes) as in
+ * mi355_mla_decode.
+ */
+int mi355_mla_decode_paged(float* out, const void* q, int64_t q_stride_row,
+                           const void* c_kv, int64_t ckv_stride_block, int64_t ckv_stride_tok,
+                           const void* k_rope, int64_t krope_stride_block, int64_t krope_stride_tok,
+                           const int32_t* block_tables, int32_t block_size, int32_t max_blocks,
+                           int32_t num_blocks,
+                           const float* cos_table, const float* sin_table, int32_t table_len,
+                           const int32_t* context_lens, const int32_t* row_seq,
+                           int32_t rows, int32_t H, int32_t R, int32_t P, int32_t max_context,
+                           float scale, int32_t dtype, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Scratch bytes mi355_mla_decode (and mi355_mla_decode_paged) needs for this shape. */
 size_t mi355_mla_decode_workspace_bytes(int32_t rows, int32_t H, int32_t R, int32_t P,
                                         int32_t max_context, int32_t dtype);
 

@@ -112,3 +112,27 @@ def latent_attention(q_cat, c_kv, k_rope, cos, sin, context_lens, scale, row_seq
         sc = (q[:, :R] @ c.T + q[:, R:] @ kr.T) * dtype(scale)
         out[r] = _softmax(sc) @ c
     return out
+
+
+def latent_attention_paged(q_cat, pool_c_kv, pool_k_rope, block_tables, block_size, cos, sin, context_lens, scale,
+                           row_seq=None, dtype=np.float64):
+    """latent_attention over a block cache (gather form): pool_c_kv [blocks, block_size, R] and
+    pool_k_rope [blocks, block_size, P]; token t of sequence s is row t % block_size of block
+    block_tables[s][t // block_size].  The rows of every sequence are gathered into dense arrays
+    (what MLAKVCache would hold, 04_mla/mini_mla.py:79-132) and handed to latent_attention."""
+    block_tables = np.asarray(block_tables)
+    seqs = block_tables.shape[0]
+    longest = int(max(context_lens)) if len(context_lens) else 0
+    R, P = pool_c_kv.shape[2], pool_k_rope.shape[2]
+    c_kv = np.zeros((seqs, max(longest, 1), R), dtype=pool_c_kv.dtype)
+    k_rope = np.zeros((seqs, max(longest, 1), P), dtype=pool_k_rope.dtype)
+    need = np.zeros(seqs, dtype=np.int64)
+    for r, n in enumerate(context_lens):
+        s = r if row_seq is None else int(row_seq[r])
+        need[s] = max(need[s], int(n))
+    for s in range(seqs):
+        for t in range(int(need[s])):
+            blk = int(block_tables[s][t // block_size])
+            c_kv[s, t] = pool_c_kv[blk, t % block_size]
+            k_rope[s, t] = pool_k_rope[blk, t % block_size]
+    return latent_attention(q_cat, c_kv, k_rope, cos, sin, context_lens, scale, row_seq, dtype)

@@ -369,3 +369,142 @@ def test_mla_decode_rejects_contexts_beyond_the_cache(ops, device):
         ops.mla_decode(q, c_kv, k_rope, cos, sin, ctx[:1], 10, 0.1)
     with pytest.raises(ValueError):
         ops.mla_decode(q, c_kv[:1], k_rope[:1], cos, sin, ctx, 10, 0.1)
+
+
+# ------------------------------------------------------------------ block cache (mi355_mla_decode_paged)
+def _scatter_into_blocks(rng, c_kv, k_rope, block_size, spare=3):
+    """A dense cache [seqs, S, .] copied into randomly chosen blocks of one pool [blocks, block_size, R + P]
+    whose other rows hold NaN; returns (pool, block_tables)."""
+    seqs, S, R = c_kv.shape
+    P = k_rope.shape[2]
+    per = (S + block_size - 1) // block_size
+    NB = seqs * per + spare
+    bt = rng.permutation(NB)[:seqs * per].reshape(seqs, per).astype(np.int32)
+    pool = torch.full((NB, block_size, R + P), float('nan'), dtype=c_kv.dtype)
+    for s in range(seqs):
+        for j in range(per):
+            n = min(block_size, S - j * block_size)
+            pool[bt[s, j], :n, :R] = c_kv[s, j * block_size:j * block_size + n]
+            pool[bt[s, j], :n, R:] = k_rope[s, j * block_size:j * block_size + n]
+    return pool, bt
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize('shape', [
+    # seqs, H, R, P, max_ctx, block_size
+    (3, 4, 32, 8, 40, 4), (2, 8, 64, 16, 100, 16), (2, 16, 128, 32, 333, 16), (2, 16, 512, 64, 700, 16),
+    (1, 20, 256, 64, 50, 8), (3, 17, 512, 64, 95, 32), (2, 32, 512, 64, 700, 16), (1, 64, 512, 64, 3000, 16),
+    (2, 16, 512, 64, 130, 1), (1, 16, 512, 64, 9000, 64),
+])
+def test_mla_decode_paged_equals_the_dense_call(ops, device, shape, dtype):
+    """A dense latent cache scattered into random blocks of a pool (every other pool row NaN): the
+    block-table call gives the dense call's result bit for bit, for every kernel (one wave, four
+    waves, 64 heads per workgroup, fp32; token splits), and both equal the oracle's gather form."""
+    seqs, H, R, P, max_ctx, bs = shape
+    if dtype == torch.float32 and not ops.mla_fp32_supported(R, P):
+        pytest.skip('rank / rope dim outside the fp32 kernel')
+    rng = np.random.default_rng(sum(shape) + 1)
+    S = max_ctx
+    q = torch.from_numpy(rng.standard_normal((seqs, H, R + P), dtype=np.float32) * 0.5).to(dtype)
+    c_kv = torch.from_numpy(rng.standard_normal((seqs, S, R), dtype=np.float32)).to(dtype)
+    k_rope = torch.from_numpy(rng.standard_normal((seqs, S, P), dtype=np.float32)).to(dtype)
+    ctx = rng.integers(1, max_ctx + 1, size=seqs).astype(np.int32)
+    ctx[0] = max_ctx
+    cos, sin = mo.rope_tables(P, S + 3)
+    pool, bt = _scatter_into_blocks(rng, c_kv, k_rope, bs)
+    cos_d, sin_d, ctx_d = torch.from_numpy(cos).to(device), torch.from_numpy(sin).to(device), torch.from_numpy(ctx).to(device)
+    dense = ops.mla_decode(q.to(device), c_kv.to(device), k_rope.to(device), cos_d, sin_d, ctx_d, max_ctx, 0.11)
+    pool_d = pool.to(device)
+    paged = ops.mla_decode_paged(q.to(device), pool_d[..., :R], pool_d[..., R:], torch.from_numpy(bt).to(device),
+                                 cos_d, sin_d, ctx_d, max_ctx, 0.11)
+    torch.cuda.synchronize()
+    assert not torch.isnan(paged).any()
+    assert torch.equal(paged.view(torch.int32), dense.view(torch.int32))
+    want = mo.latent_attention_paged(q.float().numpy(), pool[..., :R].float().numpy(), pool[..., R:].float().numpy(),
+                                     bt, bs, cos, sin, ctx, 0.11)
+    tol = dict(atol=2e-5, rtol=1e-4) if dtype == torch.float32 else TOL[dtype]
+    np.testing.assert_allclose(paged.cpu().numpy(), want, **tol)
+
+
+def test_mla_decode_paged_shared_tables_bad_ids_and_arguments(ops, device):
+    """Several query rows on one table row (row_seq: the causal rows of a chunk), block ids outside the
+    pool (clamped: no fault, other rows unaffected), zero-length rows, and refused arguments."""
+    from mi355_paged._lib import Mi355Error
+    rng = np.random.default_rng(99)
+    H, R, P, S, T, bs = 8, 128, 32, 90, 7, 16
+    q = torch.from_numpy(rng.standard_normal((2 * T, H, R + P), dtype=np.float32) * 0.5).to(torch.bfloat16)
+    c_kv = torch.from_numpy(rng.standard_normal((2, S, R), dtype=np.float32)).to(torch.bfloat16)
+    k_rope = torch.from_numpy(rng.standard_normal((2, S, P), dtype=np.float32)).to(torch.bfloat16)
+    ctx = np.concatenate([np.arange(S - T, S) + 1, np.arange(T)]).astype(np.int32)       # (second chunk: contexts 0 .. T-1)
+    row_seq = np.repeat([0, 1], T).astype(np.int32)
+    cos, sin = mo.rope_tables(P, S)
+    pool, bt = _scatter_into_blocks(rng, c_kv, k_rope, bs)
+    want = mo.latent_attention_paged(q.float().numpy(), pool[..., :R].float().numpy(), pool[..., R:].float().numpy(),
+                                     bt, bs, cos, sin, ctx, 0.2, row_seq)
+    pool_d = torch.nan_to_num(pool, nan=0.0).to(device)
+    args = (torch.from_numpy(cos).to(device), torch.from_numpy(sin).to(device), torch.from_numpy(ctx).to(device), S, 0.2)
+    out = ops.mla_decode_paged(q.to(device), pool_d[..., :R], pool_d[..., R:], torch.from_numpy(bt).to(device), *args,
+                               row_seq=torch.from_numpy(row_seq).to(device))
+    np.testing.assert_allclose(out.cpu().numpy(), want, **TOL[torch.bfloat16])
+    assert float(out[T].abs().max()) == 0.0                                              # context 0: zeros
+    bad = bt.copy()
+    bad[1, :] = [2 ** 30, -5, 10 ** 6, -1, 7, 123456][:bad.shape[1]]
+    out_bad = ops.mla_decode_paged(q.to(device), pool_d[..., :R], pool_d[..., R:], torch.from_numpy(bad).to(device), *args,
+                                   row_seq=torch.from_numpy(row_seq).to(device))
+    torch.cuda.synchronize()
+    assert torch.equal(out_bad[:T], out[:T]) and torch.isfinite(out_bad).all()
+    with pytest.raises(Mi355Error):      # block size that is not a power of two
+        p3 = torch.zeros((4, 12, R + P), dtype=torch.bfloat16, device=device)
+        ops.mla_decode_paged(q.to(device), p3[..., :R], p3[..., R:], torch.zeros((2, 8), dtype=torch.int32, device=device),
+                             *args, row_seq=torch.from_numpy(row_seq).to(device))
+    with pytest.raises(TypeError):
+        ops.mla_decode_paged(q.to(device), pool_d[..., :R], pool_d[..., R:], torch.from_numpy(bt).long().to(device), *args)
+
+
+def test_module_over_a_block_cache_matches_reference_outputs(mla_mod, device):
+    """Golden G9 through forward_paged: the rows the reference was handed as dense past_c_kv /
+    past_k_rope tensors are put into a block cache first (blocks drawn from a BlockAllocator in
+    scrambled order), the call's own rows are appended by forward_paged, and the output must be
+    the reference module's (fp32 weights, fp32 pool: atol 1e-4 like the dense module test)."""
+    import mini_vllm
+    z = load_npz('g9_mla.npz')
+    meta = json.loads(str(z['meta']))
+    checked = 0
+    for ci, m in enumerate(meta['models']):
+        cfg = m['config']
+        if not ops_fp32_ok(cfg):
+            continue
+        mod = mla_mod.MultiHeadLatentAttention(**cfg).eval()
+        state = {k[len(f'm{ci}_w::'):]: torch.from_numpy(z[k].astype(np.float32))
+                 for k in z.files if k.startswith(f'm{ci}_w::')}
+        mod.load_state_dict(state, strict=False)
+        mod = mod.to(device)
+        for name in m['calls']:
+            pre = f'm{ci}_{name}_'
+            t = lambda a: torch.from_numpy(z[a]).to(device)
+            x, pos = t(pre + 'x'), t(pre + 'pos')
+            B = x.shape[0]
+            alloc = mini_vllm.BlockAllocator(64, 8)
+            for _ in range(5):                      # scramble the free list
+                ids = [alloc.allocate() for _ in range(7)]
+                for i in ids[::2] + ids[1::2]:
+                    alloc.free(i)
+            cache = mla_mod.PagedMLAKVCache(64, 8, 1, cfg['kv_lora_rank'], cfg['qk_rope_head_dim'], device,
+                                            dtype=torch.float32, allocator=alloc)
+            if pre + 'past_c_kv' in z.files:
+                pc, pk = t(pre + 'past_c_kv'), t(pre + 'past_k_rope')
+                for b in range(B):
+                    cache.append(('seq', b), 0, pc[b], pk[b])
+            out = mod.forward_paged(x, pos, cache, 0, [('seq', b) for b in range(B)])
+            np.testing.assert_allclose(out.cpu().numpy(), z[pre + 'out'], atol=1e-4, rtol=1e-4)
+            free_before = alloc.num_free
+            for b in range(B):
+                cache.free(('seq', b))
+            assert alloc.num_free > free_before and alloc.num_free == 64
+            checked += 1
+    assert checked >= 2
+
+
+def ops_fp32_ok(cfg):
+    from mi355_paged import ops as _ops
+    return _ops.mla_fp32_supported(cfg['kv_lora_rank'], cfg['qk_rope_head_dim'])

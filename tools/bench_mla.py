@@ -1,5 +1,7 @@
 """Time mi355_mla_decode at the MLA configuration of BASELINE.json (kv_lora_rank=512, rope 64, ctx 4096).
-Usage: python tools/bench_mla.py [batch heads ctx [float32]]"""
+Usage: python tools/bench_mla.py [batch heads ctx [float32]]
+MLA_PAGED=<block size>: the same rows in randomly placed blocks of a pool, through mi355_mla_decode_paged
+(MLA_PAGED_SEQUENTIAL=1: the blocks in sequence order)."""
 import os
 import sys
 
@@ -16,6 +18,22 @@ g = torch.Generator(device=dev).manual_seed(0)
 sets = 3
 pools = [((torch.randn((B, S, R), generator=g, device=dev)).to(DT),
           (torch.randn((B, S, P), generator=g, device=dev)).to(DT)) for _ in range(sets)]
+if os.environ.get('MLA_DENSE_INTERLEAVED'):     # the dense call on rows [c_kv | k_rope] of one tensor, as a pool holds them
+    pools = [(lambda both: (both[..., :R], both[..., R:]))(torch.cat((c, k), -1)) for c, k in pools]
+BS = int(os.environ.get('MLA_PAGED', '0'))
+if BS:     # one pool [blocks, BS, R + P] per set, the sequences' blocks in a random permutation
+    per = (S + BS - 1) // BS
+    paged = []
+    for c, k in pools:
+        order = torch.randperm(B * per, generator=g, device=dev)
+        if os.environ.get('MLA_PAGED_SEQUENTIAL'):      # blocks in sequence order: what the addressing alone costs
+            order = torch.arange(B * per, device=dev)
+        pool = torch.empty((B * per, BS, R + P), dtype=DT, device=dev)
+        rows = torch.cat((c, k), -1)
+        rows = torch.nn.functional.pad(rows, (0, 0, 0, per * BS - S)).view(B * per, BS, R + P)
+        pool[order] = rows
+        paged.append((pool, order.view(B, per).to(torch.int32).contiguous()))
+    del pools
 q = (torch.randn((B, H, R + P), generator=g, device=dev) * 0.3).to(DT)
 pos = torch.arange(S, device=dev, dtype=torch.float32)
 inv = 1.0 / (10000.0 ** (torch.arange(0, P, 2, device=dev).float() / P))
@@ -29,13 +47,19 @@ for tgt in [int(x) for x in os.environ.get('MLA_TARGETS', '0,1024,2048,0').split
     n = 60
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
     for i in range(n + 5):
-        c, k = pools[i % sets]
+        if BS:
+            pool, bt = paged[i % sets]
+        else:
+            c, k = pools[i % sets]
         if i >= 5:
             ev[i - 5][0].record()
-        ops.mla_decode(q, c, k, cos, sin, ctx, S, 0.072)
+        if BS:
+            ops.mla_decode_paged(q, pool[..., :R], pool[..., R:], bt, cos, sin, ctx, S, 0.072)
+        else:
+            ops.mla_decode(q, c, k, cos, sin, ctx, S, 0.072)
         if i >= 5:
             ev[i - 5][1].record()
     torch.cuda.synchronize()
     ms = sorted(a.elapsed_time(b) for a, b in ev)[n // 2]
-    print(f"mla_decode {str(DT).split('.')[-1]} B={B} H={H} ctx={S} R={R} P={P} target={tgt or 'default'}: {ms * 1e3:.1f} us  "
+    print(f"mla_decode{f' paged (blocks of {BS})' if BS else ''} {str(DT).split('.')[-1]} B={B} H={H} ctx={S} R={R} P={P} target={tgt or 'default'}: {ms * 1e3:.1f} us  "
           f"{nbytes / ms / 1e6:.0f} GB/s ({nbytes / ms / 1e6 / 80:.1f}% of 8 TB/s)  {flops / ms / 1e9:.1f} TFLOP/s", flush=True)

@@ -64,7 +64,10 @@ int mla_f32_launch(float* out, const float* q, int64_t q_stride_row, const float
                    int64_t ckv_stride_tok, const float* k_rope, int64_t krope_stride_seq, int64_t krope_stride_tok,
                    const float* cos_table, const float* sin_table, int table_len, const int32_t* context_lens,
                    const int32_t* row_seq, int rows, int H, int R, int P, int max_context, float scale,
-                   void* workspace, size_t workspace_bytes, hipStream_t stream);
+                   void* workspace, size_t workspace_bytes, hipStream_t stream,
+                   // block-table addressing (null table: dense per-sequence rows)
+                   const int32_t* block_tables = nullptr, int block_size = 0, int max_blocks = 0, int num_blocks = 0,
+                   int64_t ckv_stride_blk = 0, int64_t krope_stride_blk = 0);
 void mla_f32_plan(int rows, int H, int max_context, int* nsplit, int* tps, size_t* ws_bytes, int R);
 // Combines token-split partials [rows, H, nsplit, R] + (max, sum) records into out (mla_decode.hip).
 int mla_merge_launch(float* out, float* ws_acc, float* ws_ml, const int32_t* ctx, int rows, int H, int R,

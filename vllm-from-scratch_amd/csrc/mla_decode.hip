@@ -52,6 +52,31 @@ struct MlaParams {
   int64_t q_stride_row, ckv_stride_seq, ckv_stride_tok, krope_stride_seq, krope_stride_tok;
   int rows, H, P, table_len, max_ctx, n_ht, nsplit, tps;
   float scale_log2e;
+  // Paged caches (the PAGED instantiations): token t of sequence s sits in block bt[s][t >> bs_shift]
+  // (clamped to the pool) at row t & bs_mask; *_stride_seq are then unused.
+  const int32_t* bt = nullptr;   // [sequences, max_blocks]
+  int64_t ckv_stride_blk = 0, krope_stride_blk = 0;
+  int bs_shift = 0, bs_mask = 0, max_blocks = 0, num_blocks = 0;
+};
+
+// Element offset of token `tok`'s row from the cache base: dense rows of one sequence (the base
+// already points at the sequence), or a row of the block the sequence's table names.
+template <bool PAGED>
+struct RowAt {
+  const MlaParams& p;
+  const int32_t* bt_row;
+  __device__ __forceinline__ RowAt(const MlaParams& p_, int seq) : p(p_), bt_row(PAGED ? p_.bt + (int64_t)seq * p_.max_blocks : nullptr) {}
+  __device__ __forceinline__ int block(int tok) const {
+    return min(max(bt_row[tok >> p.bs_shift], 0), p.num_blocks - 1);
+  }
+  __device__ __forceinline__ int64_t ckv(int tok) const {
+    if constexpr (PAGED) return (int64_t)block(tok) * p.ckv_stride_blk + (int64_t)(tok & p.bs_mask) * p.ckv_stride_tok;
+    else return (int64_t)tok * p.ckv_stride_tok;
+  }
+  __device__ __forceinline__ int64_t krope(int tok) const {
+    if constexpr (PAGED) return (int64_t)block(tok) * p.krope_stride_blk + (int64_t)(tok & p.bs_mask) * p.krope_stride_tok;
+    else return (int64_t)tok * p.krope_stride_tok;
+  }
 };
 
 template <class Tag>
@@ -84,7 +109,7 @@ struct Mma16<F16> {
   }
 };
 
-template <class Tag, int R, int PP>
+template <class Tag, int R, int PP, bool PAGED = false>
 __global__ void __launch_bounds__(kWave) mla_decode_kernel(const MlaParams p) {
   constexpr int DK = R + PP;              // key dims incl. zero padding of the rope part
   constexpr int KS = DK / 32;             // MFMA k-steps of the score product
@@ -122,8 +147,9 @@ __global__ void __launch_bounds__(kWave) mla_decode_kernel(const MlaParams p) {
   for (int ot = 0; ot < OT; ++ot) o[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -1.0e30f, l_run = 0.f;
 
-  const char* ckv = static_cast<const char*>(p.ckv) + (int64_t)seq * p.ckv_stride_seq * 2;
-  const char* krope = static_cast<const char*>(p.krope) + (int64_t)seq * p.krope_stride_seq * 2;
+  const char* ckv = static_cast<const char*>(p.ckv) + (PAGED ? 0 : (int64_t)seq * p.ckv_stride_seq * 2);
+  const char* krope = static_cast<const char*>(p.krope) + (PAGED ? 0 : (int64_t)seq * p.krope_stride_seq * 2);
+  const RowAt<PAGED> at(p, seq);
   const int half = p.P >> 1;
 
   for (int t0 = t_begin; t0 < t_end; t0 += kTok) {
@@ -134,8 +160,8 @@ __global__ void __launch_bounds__(kWave) mla_decode_kernel(const MlaParams p) {
       const int tok = min(t0 + tt, t_end - 1);        // rows past the end re-read the last one (masked below)
       const int d = dc * 8;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (d < R) v = load16<true>(ckv + ((int64_t)tok * p.ckv_stride_tok + d) * 2);
-      else if (d - R < p.P) v = load16<true>(krope + ((int64_t)tok * p.krope_stride_tok + (d - R)) * 2);
+      if (d < R) v = load16<true>(ckv + (at.ckv(tok) + d) * 2);
+      else if (d - R < p.P) v = load16<true>(krope + (at.krope(tok) + (d - R)) * 2);
       *reinterpret_cast<u32x4*>(tile + tt * ROWB + dc * 16) = v;
     }
     __syncthreads();
@@ -232,7 +258,7 @@ __global__ void __launch_bounds__(kWave) mla_decode_kernel(const MlaParams p) {
 // of the query fragments in registers and reads a quarter of the tile; each wave then owns a
 // quarter of the latent output dims for all 32 tokens.  Registers and LDS stay low enough for
 // 2 workgroups (8 waves) per CU.
-template <class Tag, int R, int PP>
+template <class Tag, int R, int PP, bool PAGED = false>
 __global__ void __launch_bounds__(256, 2) mla_decode_kernel_w4(const MlaParams p) {
   constexpr int DK = R + PP;
   constexpr int KS = DK / 32;
@@ -281,8 +307,9 @@ __global__ void __launch_bounds__(256, 2) mla_decode_kernel_w4(const MlaParams p
   for (int i = 0; i < OTW; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -1.0e30f, l_run = 0.f;
 
-  const char* ckv = static_cast<const char*>(p.ckv) + (int64_t)seq * p.ckv_stride_seq * 2;
-  const char* krope = static_cast<const char*>(p.krope) + (int64_t)seq * p.krope_stride_seq * 2;
+  const char* ckv = static_cast<const char*>(p.ckv) + (PAGED ? 0 : (int64_t)seq * p.ckv_stride_seq * 2);
+  const char* krope = static_cast<const char*>(p.krope) + (PAGED ? 0 : (int64_t)seq * p.krope_stride_seq * 2);
+  const RowAt<PAGED> at(p, seq);
   const int half = p.P >> 1;
   // rope rotation: thread = (token of the tile, group of 4 consecutive pairs), so that the 8 lanes
   // of a token read one contiguous 128-byte run of the cos / sin row
@@ -298,17 +325,44 @@ __global__ void __launch_bounds__(256, 2) mla_decode_kernel_w4(const MlaParams p
   const int kcol_ld = k_live ? kcol : 0;
   u32x4 stage_a[NLOAD], stage_b[NLOAD];
   float rc[MAXPAIR], rs[MAXPAIR];
-  auto issue_loads = [&](int t0, u32x4 (&stage)[NLOAD]) {
+  // Paged caches: the block ids of a 32-token tile, lane l holding the id of the tile's l-th block
+  // (at most 32 of them), fetched a tile before the loads that need them so that no load of the
+  // steady state waits for a table entry (a dependent table read in the address path would sit
+  // behind the prefetched tiles in the in-order load queue and drain it).
+  auto load_ids = [&](int t0) {
+    if constexpr (PAGED) return at.bt_row[min((t0 >> p.bs_shift) + (lane & 31), p.max_blocks - 1)];
+    else return 0;
+  };
+  auto issue_loads = [&](int t0, u32x4 (&stage)[NLOAD], int ids) {
+    const int blk0 = t0 >> p.bs_shift;
 #pragma unroll
     for (int i = 0; i < NCKV; ++i) {
       const int tok = min(t0 + crow + RSTEP * i, t_end - 1);   // rows past the end re-read the last one (masked later)
-      // 32-bit byte offsets from the (wave-uniform) sequence base keep the per-load address state small
-      stage[i] = load16<true>(ckv + (uint32_t)((tok * cstride + ccol * 8) * 2));
+      if constexpr (PAGED && CCH % kWave == 0) {
+        // a wave's load is one token row (kv_lora_rank 512: 64 lanes x 16 bytes): the row, its block id
+        // and the row's base address are wave-uniform, i.e. scalar work, and the load takes the
+        // scalar base plus the lane's fixed column offset
+        const int tok_u = __builtin_amdgcn_readfirstlane(tok);
+        const int id = min(max(__builtin_amdgcn_readlane(ids, (tok_u >> p.bs_shift) - blk0), 0), p.num_blocks - 1);
+        const char* rowp = ckv + ((int64_t)id * p.ckv_stride_blk + (int64_t)(tok_u & p.bs_mask) * cstride) * 2;
+        stage[i] = load16<true>(rowp + (uint32_t)(ccol * 16));
+      } else if constexpr (PAGED) {
+        const int id = min(max(__shfl(ids, (tok >> p.bs_shift) - blk0), 0), p.num_blocks - 1);
+        stage[i] = load16<true>(ckv + ((int64_t)id * p.ckv_stride_blk + (int64_t)((tok & p.bs_mask) * cstride + ccol * 8)) * 2);
+      } else {
+        // 32-bit byte offsets from the (wave-uniform) sequence base keep the per-load address state small
+        stage[i] = load16<true>(ckv + (uint32_t)((tok * cstride + ccol * 8) * 2));
+      }
     }
     // unconditional (address clamped into the row) so the compiler can count outstanding loads
     // exactly; lanes beyond the rope width are zeroed when the stage is written to LDS
     const int tok = min(t0 + min(krow, kTok2 - 1), t_end - 1);
-    stage[NCKV] = load16<true>(krope + (uint32_t)((tok * rstride + kcol_ld * 8) * 2));
+    if constexpr (PAGED) {
+      const int id = min(max(__shfl(ids, (tok >> p.bs_shift) - blk0), 0), p.num_blocks - 1);
+      stage[NCKV] = load16<true>(krope + ((int64_t)id * p.krope_stride_blk + (int64_t)((tok & p.bs_mask) * rstride + kcol_ld * 8)) * 2);
+    } else {
+      stage[NCKV] = load16<true>(krope + (uint32_t)((tok * rstride + kcol_ld * 8) * 2));
+    }
   };
   // cos / sin of the rope pairs this thread rotates in tile t0.  Issued BEFORE the data loads
   // of the tile after it, so waiting for them never waits for those.
@@ -328,7 +382,7 @@ __global__ void __launch_bounds__(256, 2) mla_decode_kernel_w4(const MlaParams p
 
   // One tile: registers -> LDS, rotate the rope part, refill the same registers with the tile
   // two steps ahead, then scores / softmax / weighted sum from LDS.
-  auto process = [&](int t, u32x4 (&stage)[NLOAD], auto steady) {
+  auto process = [&](int t, u32x4 (&stage)[NLOAD], int& ids_mine, int& ids_other, auto steady) {
     const int t0 = t_begin + t * kTok2;
     unsigned char* tile = tiles[t & 1];
 #pragma unroll
@@ -357,12 +411,16 @@ __global__ void __launch_bounds__(256, 2) mla_decode_kernel_w4(const MlaParams p
       *reinterpret_cast<u32x2*>(kr + half * 2) = u32x2{Mma16<Tag>::pack2(nhi[0], nhi[1]), Mma16<Tag>::pack2(nhi[2], nhi[3])};
     }
     __syncthreads();
+    // (ids_mine: the ids of tile t + 2, fetched a step ago; the ids of tile t + 3 go out ahead of
+    // tile t + 2's loads, so that the next step's wait for them does not wait for those loads)
     if constexpr (decltype(steady)::value) {   // main loop: both refills exist, no branches around the loads
       issue_rope_factors(t0 + kTok2);
-      issue_loads(t0 + 2 * kTok2, stage);
+      ids_other = load_ids(t0 + 3 * kTok2);
+      issue_loads(t0 + 2 * kTok2, stage, ids_mine);
     } else {
       if (t + 1 < ntiles) issue_rope_factors(t0 + kTok2);
-      if (t + 2 < ntiles) issue_loads(t0 + 2 * kTok2, stage);
+      if (t + 3 < ntiles) ids_other = load_ids(t0 + 3 * kTok2);
+      if (t + 2 < ntiles) issue_loads(t0 + 2 * kTok2, stage, ids_mine);
     }
 
     // partial S^T (16 tokens x 16 heads over half of the key dims), exchanged through LDS
@@ -429,23 +487,26 @@ __global__ void __launch_bounds__(256, 2) mla_decode_kernel_w4(const MlaParams p
   // Issue order in the steady state is data(t+2), factors(t+3), data(t+3), ...; the prologue
   // follows the same order so the compiler's outstanding-load counts agree on both loop edges.
   int t = 0;
+  int ids_a = load_ids(t_begin), ids_b = load_ids(t_begin + kTok2);   // (paged caches; see load_ids)
   if (ntiles >= 4) {
-    issue_loads(t_begin, stage_a);
+    issue_loads(t_begin, stage_a, ids_a);
+    ids_a = load_ids(t_begin + 2 * kTok2);
     issue_rope_factors(t_begin);
-    issue_loads(t_begin + kTok2, stage_b);
+    issue_loads(t_begin + kTok2, stage_b, ids_b);
     do {
-      process(t, stage_a, std::true_type{});
-      process(t + 1, stage_b, std::true_type{});
+      process(t, stage_a, ids_a, ids_b, std::true_type{});
+      process(t + 1, stage_b, ids_b, ids_a, std::true_type{});
       t += 2;
     } while (t + 3 < ntiles);
   } else if (ntiles > 0) {
-    issue_loads(t_begin, stage_a);
+    issue_loads(t_begin, stage_a, ids_a);
+    if (ntiles > 2) ids_a = load_ids(t_begin + 2 * kTok2);
     issue_rope_factors(t_begin);
-    if (ntiles > 1) issue_loads(t_begin + kTok2, stage_b);
+    if (ntiles > 1) issue_loads(t_begin + kTok2, stage_b, ids_b);
   }
   for (; t < ntiles; t += 2) {   // last one to three tiles
-    process(t, stage_a, std::false_type{});
-    if (t + 1 < ntiles) process(t + 1, stage_b, std::false_type{});
+    process(t, stage_a, ids_a, ids_b, std::false_type{});
+    if (t + 1 < ntiles) process(t + 1, stage_b, ids_b, ids_a, std::false_type{});
   }
 
   if (!head_ok) return;
@@ -474,7 +535,7 @@ __global__ void __launch_bounds__(256, 2) mla_decode_kernel_w4(const MlaParams p
 // (one wave per SIMD) per CU, with the two-tile register prefetch covering the memory latency.
 // Per 32-token tile a wave issues 2 x KS + R / 16 matrix instructions (68 at R = 512, about a
 // third of the time the tile's 36 KiB take to arrive at the CU's share of HBM bandwidth).
-template <class Tag, int R, int PP>
+template <class Tag, int R, int PP, bool PAGED = false>
 __global__ void __launch_bounds__(256) mla_decode_kernel_mh(const MlaParams p) {
   constexpr int DK = R + PP;
   constexpr int KS = DK / 32;
@@ -523,8 +584,9 @@ __global__ void __launch_bounds__(256) mla_decode_kernel_mh(const MlaParams p) {
   for (int i = 0; i < OT; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -1.0e30f, l_run = 0.f;
 
-  const char* ckv = static_cast<const char*>(p.ckv) + (int64_t)seq * p.ckv_stride_seq * 2;
-  const char* krope = static_cast<const char*>(p.krope) + (int64_t)seq * p.krope_stride_seq * 2;
+  const char* ckv = static_cast<const char*>(p.ckv) + (PAGED ? 0 : (int64_t)seq * p.ckv_stride_seq * 2);
+  const char* krope = static_cast<const char*>(p.krope) + (PAGED ? 0 : (int64_t)seq * p.krope_stride_seq * 2);
+  const RowAt<PAGED> at(p, seq);
   const int half = p.P >> 1;
   // rope rotation: thread = (token of the tile, group of 4 consecutive pairs), so that the 8 lanes
   // of a token read one contiguous 128-byte run of the cos / sin row
@@ -540,17 +602,44 @@ __global__ void __launch_bounds__(256) mla_decode_kernel_mh(const MlaParams p) {
   const int kcol_ld = k_live ? kcol : 0;
   u32x4 stage_a[NLOAD], stage_b[NLOAD];
   float rc[MAXPAIR], rs[MAXPAIR];
-  auto issue_loads = [&](int t0, u32x4 (&stage)[NLOAD]) {
+  // Paged caches: the block ids of a 32-token tile, lane l holding the id of the tile's l-th block
+  // (at most 32 of them), fetched a tile before the loads that need them so that no load of the
+  // steady state waits for a table entry (a dependent table read in the address path would sit
+  // behind the prefetched tiles in the in-order load queue and drain it).
+  auto load_ids = [&](int t0) {
+    if constexpr (PAGED) return at.bt_row[min((t0 >> p.bs_shift) + (lane & 31), p.max_blocks - 1)];
+    else return 0;
+  };
+  auto issue_loads = [&](int t0, u32x4 (&stage)[NLOAD], int ids) {
+    const int blk0 = t0 >> p.bs_shift;
 #pragma unroll
     for (int i = 0; i < NCKV; ++i) {
       const int tok = min(t0 + crow + RSTEP * i, t_end - 1);   // rows past the end re-read the last one (masked later)
-      // 32-bit byte offsets from the (wave-uniform) sequence base keep the per-load address state small
-      stage[i] = load16<true>(ckv + (uint32_t)((tok * cstride + ccol * 8) * 2));
+      if constexpr (PAGED && CCH % kWave == 0) {
+        // a wave's load is one token row (kv_lora_rank 512: 64 lanes x 16 bytes): the row, its block id
+        // and the row's base address are wave-uniform, i.e. scalar work, and the load takes the
+        // scalar base plus the lane's fixed column offset
+        const int tok_u = __builtin_amdgcn_readfirstlane(tok);
+        const int id = min(max(__builtin_amdgcn_readlane(ids, (tok_u >> p.bs_shift) - blk0), 0), p.num_blocks - 1);
+        const char* rowp = ckv + ((int64_t)id * p.ckv_stride_blk + (int64_t)(tok_u & p.bs_mask) * cstride) * 2;
+        stage[i] = load16<true>(rowp + (uint32_t)(ccol * 16));
+      } else if constexpr (PAGED) {
+        const int id = min(max(__shfl(ids, (tok >> p.bs_shift) - blk0), 0), p.num_blocks - 1);
+        stage[i] = load16<true>(ckv + ((int64_t)id * p.ckv_stride_blk + (int64_t)((tok & p.bs_mask) * cstride + ccol * 8)) * 2);
+      } else {
+        // 32-bit byte offsets from the (wave-uniform) sequence base keep the per-load address state small
+        stage[i] = load16<true>(ckv + (uint32_t)((tok * cstride + ccol * 8) * 2));
+      }
     }
     // unconditional (address clamped into the row) so the compiler can count outstanding loads
     // exactly; lanes beyond the rope width are zeroed when the stage is written to LDS
     const int tok = min(t0 + min(krow, kTok2 - 1), t_end - 1);
-    stage[NCKV] = load16<true>(krope + (uint32_t)((tok * rstride + kcol_ld * 8) * 2));
+    if constexpr (PAGED) {
+      const int id = min(max(__shfl(ids, (tok >> p.bs_shift) - blk0), 0), p.num_blocks - 1);
+      stage[NCKV] = load16<true>(krope + ((int64_t)id * p.krope_stride_blk + (int64_t)((tok & p.bs_mask) * rstride + kcol_ld * 8)) * 2);
+    } else {
+      stage[NCKV] = load16<true>(krope + (uint32_t)((tok * rstride + kcol_ld * 8) * 2));
+    }
   };
   // cos / sin of the rope pairs this thread rotates in tile t0.  Issued BEFORE the data loads
   // of the tile after it, so waiting for them never waits for those.
@@ -570,7 +659,7 @@ __global__ void __launch_bounds__(256) mla_decode_kernel_mh(const MlaParams p) {
 
   // One tile: registers -> LDS, rotate the rope part, refill the same registers with the tile
   // two steps ahead, then scores / softmax / weighted sum from LDS.
-  auto process = [&](int t, u32x4 (&stage)[NLOAD], auto steady) {
+  auto process = [&](int t, u32x4 (&stage)[NLOAD], int& ids_mine, int& ids_other, auto steady) {
     const int t0 = t_begin + t * kTok2;
     unsigned char* tile = tiles[t & 1];
 #pragma unroll
@@ -599,12 +688,16 @@ __global__ void __launch_bounds__(256) mla_decode_kernel_mh(const MlaParams p) {
       *reinterpret_cast<u32x2*>(kr + half * 2) = u32x2{Mma16<Tag>::pack2(nhi[0], nhi[1]), Mma16<Tag>::pack2(nhi[2], nhi[3])};
     }
     __syncthreads();
+    // (ids_mine: the ids of tile t + 2, fetched a step ago; the ids of tile t + 3 go out ahead of
+    // tile t + 2's loads, so that the next step's wait for them does not wait for those loads)
     if constexpr (decltype(steady)::value) {   // main loop: both refills exist, no branches around the loads
       issue_rope_factors(t0 + kTok2);
-      issue_loads(t0 + 2 * kTok2, stage);
+      ids_other = load_ids(t0 + 3 * kTok2);
+      issue_loads(t0 + 2 * kTok2, stage, ids_mine);
     } else {
       if (t + 1 < ntiles) issue_rope_factors(t0 + kTok2);
-      if (t + 2 < ntiles) issue_loads(t0 + 2 * kTok2, stage);
+      if (t + 3 < ntiles) ids_other = load_ids(t0 + 3 * kTok2);
+      if (t + 2 < ntiles) issue_loads(t0 + 2 * kTok2, stage, ids_mine);
     }
 
     if (!wave_live) return;
@@ -695,23 +788,26 @@ __global__ void __launch_bounds__(256) mla_decode_kernel_mh(const MlaParams p) {
   // Issue order in the steady state is data(t+2), factors(t+3), data(t+3), ...; the prologue
   // follows the same order so the compiler's outstanding-load counts agree on both loop edges.
   int t = 0;
+  int ids_a = load_ids(t_begin), ids_b = load_ids(t_begin + kTok2);   // (paged caches; see load_ids)
   if (ntiles >= 4) {
-    issue_loads(t_begin, stage_a);
+    issue_loads(t_begin, stage_a, ids_a);
+    ids_a = load_ids(t_begin + 2 * kTok2);
     issue_rope_factors(t_begin);
-    issue_loads(t_begin + kTok2, stage_b);
+    issue_loads(t_begin + kTok2, stage_b, ids_b);
     do {
-      process(t, stage_a, std::true_type{});
-      process(t + 1, stage_b, std::true_type{});
+      process(t, stage_a, ids_a, ids_b, std::true_type{});
+      process(t + 1, stage_b, ids_b, ids_a, std::true_type{});
       t += 2;
     } while (t + 3 < ntiles);
   } else if (ntiles > 0) {
-    issue_loads(t_begin, stage_a);
+    issue_loads(t_begin, stage_a, ids_a);
+    if (ntiles > 2) ids_a = load_ids(t_begin + 2 * kTok2);
     issue_rope_factors(t_begin);
-    if (ntiles > 1) issue_loads(t_begin + kTok2, stage_b);
+    if (ntiles > 1) issue_loads(t_begin + kTok2, stage_b, ids_b);
   }
   for (; t < ntiles; t += 2) {   // last one to three tiles
-    process(t, stage_a, std::false_type{});
-    if (t + 1 < ntiles) process(t + 1, stage_b, std::false_type{});
+    process(t, stage_a, ids_a, ids_b, std::false_type{});
+    if (t + 1 < ntiles) process(t + 1, stage_b, ids_b, ids_a, std::false_type{});
   }
 
   if (!head_ok) return;
@@ -793,18 +889,18 @@ int mla_plan(int rows, int H, int R, int P, int max_context, int dtype, MlaPlan*
   return 0;
 }
 
-template <class Tag, int R>
+template <class Tag, int R, bool PAGED>
 int launch_r(const MlaParams& p, bool many, hipStream_t s) {
   const int64_t grid = (int64_t)p.rows * p.nsplit * p.n_ht;
   if constexpr (R >= 128) {
     if (many) {
-      if (p.P <= 32) hipLaunchKernelGGL((mla_decode_kernel_mh<Tag, R, 32>), dim3((unsigned)grid), dim3(256), 0, s, p);
-      else hipLaunchKernelGGL((mla_decode_kernel_mh<Tag, R, 64>), dim3((unsigned)grid), dim3(256), 0, s, p);
-    } else if (p.P <= 32) hipLaunchKernelGGL((mla_decode_kernel_w4<Tag, R, 32>), dim3((unsigned)grid), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((mla_decode_kernel_w4<Tag, R, 64>), dim3((unsigned)grid), dim3(256), 0, s, p);
+      if (p.P <= 32) hipLaunchKernelGGL((mla_decode_kernel_mh<Tag, R, 32, PAGED>), dim3((unsigned)grid), dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((mla_decode_kernel_mh<Tag, R, 64, PAGED>), dim3((unsigned)grid), dim3(256), 0, s, p);
+    } else if (p.P <= 32) hipLaunchKernelGGL((mla_decode_kernel_w4<Tag, R, 32, PAGED>), dim3((unsigned)grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((mla_decode_kernel_w4<Tag, R, 64, PAGED>), dim3((unsigned)grid), dim3(256), 0, s, p);
   } else {
-    if (p.P <= 32) hipLaunchKernelGGL((mla_decode_kernel<Tag, R, 32>), dim3((unsigned)grid), dim3(kWave), 0, s, p);
-    else hipLaunchKernelGGL((mla_decode_kernel<Tag, R, 64>), dim3((unsigned)grid), dim3(kWave), 0, s, p);
+    if (p.P <= 32) hipLaunchKernelGGL((mla_decode_kernel<Tag, R, 32, PAGED>), dim3((unsigned)grid), dim3(kWave), 0, s, p);
+    else hipLaunchKernelGGL((mla_decode_kernel<Tag, R, 64, PAGED>), dim3((unsigned)grid), dim3(kWave), 0, s, p);
   }
   if (int rc = check_launch("mla_decode_kernel")) return rc;
   if (p.nsplit > 1) {
@@ -815,14 +911,14 @@ int launch_r(const MlaParams& p, bool many, hipStream_t s) {
   return 0;
 }
 
-template <class Tag>
+template <class Tag, bool PAGED>
 int launch_t(int R, const MlaParams& p, bool many, hipStream_t s) {
   switch (R) {
-    case 32: return launch_r<Tag, 32>(p, many, s);
-    case 64: return launch_r<Tag, 64>(p, many, s);
-    case 128: return launch_r<Tag, 128>(p, many, s);
-    case 256: return launch_r<Tag, 256>(p, many, s);
-    case 512: return launch_r<Tag, 512>(p, many, s);
+    case 32: return launch_r<Tag, 32, PAGED>(p, many, s);
+    case 64: return launch_r<Tag, 64, PAGED>(p, many, s);
+    case 128: return launch_r<Tag, 128, PAGED>(p, many, s);
+    case 256: return launch_r<Tag, 256, PAGED>(p, many, s);
+    case 512: return launch_r<Tag, 512, PAGED>(p, many, s);
   }
   return fail(MI355_EUNSUPPORTED, "mla_decode: kv_lora_rank %d", R);
 }
@@ -872,44 +968,64 @@ extern "C" size_t mi355_mla_decode_workspace_bytes(int32_t rows, int32_t H, int3
   return pl.ws_bytes;
 }
 
-extern "C" int mi355_mla_decode(float* out, const void* q, int64_t q_stride_row, const void* c_kv,
-                                int64_t ckv_stride_seq, int64_t ckv_stride_tok, const void* k_rope,
-                                int64_t krope_stride_seq, int64_t krope_stride_tok, const float* cos_table,
-                                const float* sin_table, int32_t table_len, const int32_t* context_lens,
-                                const int32_t* row_seq, int32_t rows, int32_t H, int32_t R, int32_t P,
-                                int32_t max_context, float scale, int32_t dtype, void* workspace,
-                                size_t workspace_bytes, void* stream) {
+namespace mi355 {
+namespace {
+// Block-table addressing of mi355_mla_decode_paged (null table: dense per-sequence rows).
+struct MlaPaging {
+  const int32_t* bt = nullptr;
+  int block_size = 0, max_blocks = 0, num_blocks = 0;
+  int64_t ckv_stride_blk = 0, krope_stride_blk = 0;
+};
+
+int mla_decode_impl(const char* what, float* out, const void* q, int64_t q_stride_row, const void* c_kv,
+                    int64_t ckv_stride_seq, int64_t ckv_stride_tok, const void* k_rope, int64_t krope_stride_seq,
+                    int64_t krope_stride_tok, const float* cos_table, const float* sin_table, int32_t table_len,
+                    const int32_t* context_lens, const int32_t* row_seq, int32_t rows, int32_t H, int32_t R,
+                    int32_t P, int32_t max_context, float scale, int32_t dtype, void* workspace,
+                    size_t workspace_bytes, void* stream, const MlaPaging& pg) {
   if (rows == 0) return 0;
   if (!out || !q || !c_kv || !k_rope || !cos_table || !sin_table || !context_lens)
-    return fail(MI355_EINVAL, "mla_decode: null pointer argument");
+    return fail(MI355_EINVAL, "%s: null pointer argument", what);
+  const bool paged = pg.bt != nullptr;
+  const int epl = dtype == MI355_F32 ? 4 : 8;
+  if (paged) {
+    if (pg.block_size <= 0 || ilog2_exact(pg.block_size) < 0)
+      return fail(MI355_EUNSUPPORTED, "%s: block_size %d is not a power of two", what, pg.block_size);
+    if (pg.max_blocks <= 0 || pg.num_blocks <= 0) return fail(MI355_EINVAL, "%s: max_blocks / num_blocks", what);
+    if (pg.ckv_stride_blk <= 0 || pg.krope_stride_blk <= 0 || pg.ckv_stride_blk % epl || pg.krope_stride_blk % epl)
+      return fail(MI355_EINVAL, "%s: block strides must keep rows 16-byte aligned", what);
+    if ((int64_t)max_context > (int64_t)pg.max_blocks * pg.block_size) max_context = pg.max_blocks * pg.block_size;
+  }
   if (dtype == MI355_F32) {
-    if (rows < 0 || H <= 0 || max_context < 0 || table_len <= 0) return fail(MI355_EINVAL, "mla_decode: bad shape");
+    if (rows < 0 || H <= 0 || max_context < 0 || table_len <= 0) return fail(MI355_EINVAL, "%s: bad shape", what);
     if (!mla_f32_supported(R, P))
-      return fail(MI355_EUNSUPPORTED, "mla_decode (fp32): kv_lora_rank %d / rope dim %d outside {32,64,128} x {8,16,32,64} and {256,512} x {32,64}",
-                  R, P);
+      return fail(MI355_EUNSUPPORTED, "%s (fp32): kv_lora_rank %d / rope dim %d outside {32,64,128} x {8,16,32,64} and {256,512} x {32,64}",
+                  what, R, P);
     if (q_stride_row % 4 || ckv_stride_tok % 4 || ckv_stride_seq % 4 || q_stride_row < (int64_t)H * (R + P) ||
         ckv_stride_tok < R || krope_stride_tok < P)
-      return fail(MI355_EINVAL, "mla_decode: strides must keep rows 16-byte aligned");
+      return fail(MI355_EINVAL, "%s: strides must keep rows 16-byte aligned", what);
     if (((uintptr_t)out | (uintptr_t)q | (uintptr_t)c_kv) & 15)
-      return fail(MI355_EINVAL, "mla_decode: tensors must be 16-byte aligned");
+      return fail(MI355_EINVAL, "%s: tensors must be 16-byte aligned", what);
     return mla_f32_launch(out, static_cast<const float*>(q), q_stride_row, static_cast<const float*>(c_kv),
                           ckv_stride_seq, ckv_stride_tok, static_cast<const float*>(k_rope), krope_stride_seq,
                           krope_stride_tok, cos_table, sin_table, table_len, context_lens, row_seq, rows, H, R, P,
-                          max_context, scale, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+                          max_context, scale, workspace, workspace_bytes, static_cast<hipStream_t>(stream), pg.bt,
+                          pg.block_size, pg.max_blocks, pg.num_blocks, pg.ckv_stride_blk, pg.krope_stride_blk);
   }
   MlaPlan pl;
   if (int rc = mla_plan(rows, H, R, P, max_context, dtype, &pl)) return rc;
-  if (table_len <= 0) return fail(MI355_EINVAL, "mla_decode: empty cos/sin table");
+  if (table_len <= 0) return fail(MI355_EINVAL, "%s: empty cos/sin table", what);
   if (q_stride_row % 8 || ckv_stride_tok % 8 || ckv_stride_seq % 8 || krope_stride_tok % 8 || krope_stride_seq % 8 ||
       q_stride_row < (int64_t)H * (R + P) || ckv_stride_tok < R || krope_stride_tok < P)
-    return fail(MI355_EINVAL, "mla_decode: strides must keep rows 16-byte aligned");
+    return fail(MI355_EINVAL, "%s: strides must keep rows 16-byte aligned", what);
   if (((uintptr_t)out | (uintptr_t)q | (uintptr_t)c_kv | (uintptr_t)k_rope | (uintptr_t)cos_table |
        (uintptr_t)sin_table) & 15)
-    return fail(MI355_EINVAL, "mla_decode: tensors must be 16-byte aligned");
-  if ((int64_t)max_context * ckv_stride_tok >= (1LL << 30) || (int64_t)max_context * krope_stride_tok >= (1LL << 30))
-    return fail(MI355_EUNSUPPORTED, "mla_decode: one sequence's cache must span < 2^30 elements");
+    return fail(MI355_EINVAL, "%s: tensors must be 16-byte aligned", what);
+  // (dense rows are addressed with 32-bit offsets from the sequence's base; blocks with 64-bit ones)
+  if (!paged && ((int64_t)max_context * ckv_stride_tok >= (1LL << 30) || (int64_t)max_context * krope_stride_tok >= (1LL << 30)))
+    return fail(MI355_EUNSUPPORTED, "%s: one sequence's cache must span < 2^30 elements", what);
   if (pl.ws_bytes && (!workspace || workspace_bytes < pl.ws_bytes || ((uintptr_t)workspace & 15)))
-    return fail(MI355_EWORKSPACE, "mla_decode: need %zu workspace bytes (16-B aligned), got %zu", pl.ws_bytes,
+    return fail(MI355_EWORKSPACE, "%s: need %zu workspace bytes (16-B aligned), got %zu", what, pl.ws_bytes,
                 workspace ? workspace_bytes : (size_t)0);
   MlaParams p;
   p.out = out;
@@ -937,5 +1053,53 @@ extern "C" int mi355_mla_decode(float* out, const void* q, int64_t q_stride_row,
   p.tps = pl.tps;
   p.scale_log2e = scale * 1.4426950408889634f;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  return dtype == MI355_BF16 ? launch_t<BF16>(R, p, pl.many, s) : launch_t<F16>(R, p, pl.many, s);
+  if (paged) {
+    p.bt = pg.bt;
+    p.ckv_stride_blk = pg.ckv_stride_blk;
+    p.krope_stride_blk = pg.krope_stride_blk;
+    p.bs_shift = ilog2_exact(pg.block_size);
+    p.bs_mask = pg.block_size - 1;
+    p.max_blocks = pg.max_blocks;
+    p.num_blocks = pg.num_blocks;
+    return dtype == MI355_BF16 ? launch_t<BF16, true>(R, p, pl.many, s) : launch_t<F16, true>(R, p, pl.many, s);
+  }
+  return dtype == MI355_BF16 ? launch_t<BF16, false>(R, p, pl.many, s) : launch_t<F16, false>(R, p, pl.many, s);
+}
+}  // namespace
+}  // namespace mi355
+
+extern "C" int mi355_mla_decode(float* out, const void* q, int64_t q_stride_row, const void* c_kv,
+                                int64_t ckv_stride_seq, int64_t ckv_stride_tok, const void* k_rope,
+                                int64_t krope_stride_seq, int64_t krope_stride_tok, const float* cos_table,
+                                const float* sin_table, int32_t table_len, const int32_t* context_lens,
+                                const int32_t* row_seq, int32_t rows, int32_t H, int32_t R, int32_t P,
+                                int32_t max_context, float scale, int32_t dtype, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  return mla_decode_impl("mla_decode", out, q, q_stride_row, c_kv, ckv_stride_seq, ckv_stride_tok, k_rope,
+                         krope_stride_seq, krope_stride_tok, cos_table, sin_table, table_len, context_lens, row_seq,
+                         rows, H, R, P, max_context, scale, dtype, workspace, workspace_bytes, stream, MlaPaging{});
+}
+
+extern "C" int mi355_mla_decode_paged(float* out, const void* q, int64_t q_stride_row, const void* c_kv,
+                                      int64_t ckv_stride_block, int64_t ckv_stride_tok, const void* k_rope,
+                                      int64_t krope_stride_block, int64_t krope_stride_tok,
+                                      const int32_t* block_tables, int32_t block_size, int32_t max_blocks,
+                                      int32_t num_blocks, const float* cos_table, const float* sin_table,
+                                      int32_t table_len, const int32_t* context_lens, const int32_t* row_seq,
+                                      int32_t rows, int32_t H, int32_t R, int32_t P, int32_t max_context,
+                                      float scale, int32_t dtype, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+  if (rows == 0) return 0;
+  if (!block_tables) return fail(MI355_EINVAL, "mla_decode_paged: null block table");
+  MlaPaging pg;
+  pg.bt = block_tables;
+  pg.block_size = block_size;
+  pg.max_blocks = max_blocks;
+  pg.num_blocks = num_blocks;
+  pg.ckv_stride_blk = ckv_stride_block;
+  pg.krope_stride_blk = krope_stride_block;
+  // (the per-sequence strides of the dense form are unused; 8 keeps their alignment checks quiet)
+  return mla_decode_impl("mla_decode_paged", out, q, q_stride_row, c_kv, 8, ckv_stride_tok, k_rope, 8, krope_stride_tok,
+                         cos_table, sin_table, table_len, context_lens, row_seq, rows, H, R, P, max_context, scale,
+                         dtype, workspace, workspace_bytes, stream, pg);
 }

@@ -51,6 +51,11 @@ struct MlaF32Params {
   float* ws_acc;   // [rows, H, nsplit, R] un-normalised partial outputs (nsplit > 1)
   float* ws_ml;    // [rows, H, nsplit, 2] (running maximum in log2 units, sum)
   float scale_log2e;
+  // Paged caches (the PAGED instantiations): token t of sequence s sits in block bt[s][t >> bs_shift]
+  // (clamped to the pool) at row t & bs_mask; the per-sequence strides are then unused.
+  const int32_t* bt = nullptr;
+  int64_t ckv_stride_blk = 0, krope_stride_blk = 0;
+  int bs_shift = 0, bs_mask = 0, max_blocks = 0, num_blocks = 0;
 };
 
 __device__ __forceinline__ f32x4v mma4(float a, float b, f32x4v c) {
@@ -111,7 +116,7 @@ __device__ __forceinline__ void load_run(const float* src, float (&dst)[RS]) {
   }
 }
 
-template <int R, int P, int WAVES, bool VEC>
+template <int R, int P, int WAVES, bool VEC, bool PAGED>
 __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) mla_decode_f32_kernel(const MlaF32Params p) {
   constexpr int Q = R / WAVES;            // latent dims per wave
   constexpr int NJ = Q / 16;              // 16-dim groups per wave
@@ -152,8 +157,9 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) mla_decode_f32
   for (int j = 0; j < NJ; ++j) o[j] = f32x4v{0.f, 0.f, 0.f, 0.f};
   float m_run = -1.0e30f, l_run = 0.f;
 
-  const float* ckv_seq = p.ckv + (int64_t)seq * p.ckv_stride_seq + Q * wave;
-  const float* kr_seq = p.krope + (int64_t)seq * p.krope_stride_seq;
+  const float* ckv_seq = p.ckv + (PAGED ? 0 : (int64_t)seq * p.ckv_stride_seq) + Q * wave;
+  const float* kr_seq = p.krope + (PAGED ? 0 : (int64_t)seq * p.krope_stride_seq);
+  const int32_t* bt_row = PAGED ? p.bt + (int64_t)seq * p.max_blocks : nullptr;
 
   // A tile in registers: this lane's token row (clamped to the context; rows past it are masked below)
   struct Tile {
@@ -162,10 +168,16 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) mla_decode_f32
   };
   auto load_tile = [&](int t0, Tile& x) __attribute__((always_inline)) {
     const int key = min(t0 + c, max(ctx - 1, 0));           // (t0 counts from token 0 of the sequence)
-    const float* krow = ckv_seq + (int64_t)key * p.ckv_stride_tok;
+    int64_t ckv_at = (int64_t)key * p.ckv_stride_tok, kr_at = (int64_t)key * p.krope_stride_tok;
+    if constexpr (PAGED) {
+      const int blk = min(max(bt_row[key >> p.bs_shift], 0), p.num_blocks - 1), r = key & p.bs_mask;
+      ckv_at = (int64_t)blk * p.ckv_stride_blk + (int64_t)r * p.ckv_stride_tok;
+      kr_at = (int64_t)blk * p.krope_stride_blk + (int64_t)r * p.krope_stride_tok;
+    }
+    const float* krow = ckv_seq + ckv_at;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) x.k[j] = *reinterpret_cast<const f32x4v*>(krow + 16 * j + 4 * g);
-    const float* rrow = kr_seq + (int64_t)key * p.krope_stride_tok;
+    const float* rrow = kr_seq + kr_at;
     const int trow = min(key, p.table_len - 1) * P;
     load_run<RS, VEC>(rrow + rbase, x.v);
     load_run<RS, VEC>(p.cos_t + trow + rbase, x.cs);
@@ -319,8 +331,11 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) mla_decode_f32
 
 template <int R, int P, int WAVES>
 void launch_rp(const MlaF32Params& p, dim3 g, bool vec, hipStream_t s) {
-  if (vec) hipLaunchKernelGGL((mla_decode_f32_kernel<R, P, WAVES, true>), g, dim3(WAVES * 64), 0, s, p);
-  else hipLaunchKernelGGL((mla_decode_f32_kernel<R, P, WAVES, false>), g, dim3(WAVES * 64), 0, s, p);
+  if (p.bt) {
+    if (vec) hipLaunchKernelGGL((mla_decode_f32_kernel<R, P, WAVES, true, true>), g, dim3(WAVES * 64), 0, s, p);
+    else hipLaunchKernelGGL((mla_decode_f32_kernel<R, P, WAVES, false, true>), g, dim3(WAVES * 64), 0, s, p);
+  } else if (vec) hipLaunchKernelGGL((mla_decode_f32_kernel<R, P, WAVES, true, false>), g, dim3(WAVES * 64), 0, s, p);
+  else hipLaunchKernelGGL((mla_decode_f32_kernel<R, P, WAVES, false, false>), g, dim3(WAVES * 64), 0, s, p);
 }
 
 // vec: rope rows, q's rope part and the cos / sin tables may be read in 16-byte pieces
@@ -371,8 +386,18 @@ int mla_f32_launch(float* out, const float* q, int64_t q_stride_row, const float
                    int64_t ckv_stride_tok, const float* k_rope, int64_t krope_stride_seq, int64_t krope_stride_tok,
                    const float* cos_table, const float* sin_table, int table_len, const int32_t* context_lens,
                    const int32_t* row_seq, int rows, int H, int R, int P, int max_context, float scale,
-                   void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                   void* workspace, size_t workspace_bytes, hipStream_t stream, const int32_t* block_tables,
+                   int block_size, int max_blocks, int num_blocks, int64_t ckv_stride_blk, int64_t krope_stride_blk) {
   MlaF32Params p;
+  if (block_tables) {   // (block_size is a power of two: checked by the caller)
+    p.bt = block_tables;
+    p.bs_shift = ilog2_exact(block_size);
+    p.bs_mask = block_size - 1;
+    p.max_blocks = max_blocks;
+    p.num_blocks = num_blocks;
+    p.ckv_stride_blk = ckv_stride_blk;
+    p.krope_stride_blk = krope_stride_blk;
+  }
   size_t need = 0;
   mla_f32_plan(rows, H, max_context, &p.nsplit, &p.tps, &need, R);
   if (need && (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)))
@@ -401,7 +426,7 @@ int mla_f32_launch(float* out, const float* q, int64_t q_stride_row, const float
   p.scale_log2e = scale * 1.4426950408889634f;
   // (q rows are 16-byte aligned by the caller's checks and R is a multiple of 4, so q's rope part is too)
   const bool vec = !(((uintptr_t)k_rope | (uintptr_t)cos_table | (uintptr_t)sin_table) & 15) &&
-                   krope_stride_tok % 4 == 0 && krope_stride_seq % 4 == 0;
+                   krope_stride_tok % 4 == 0 && (block_tables ? krope_stride_blk % 4 == 0 : krope_stride_seq % 4 == 0);
   switch (R) {
     case 32: return launch_r<32>(p, P, vec, stream);
     case 64: return launch_r<64>(p, P, vec, stream);

@@ -496,6 +496,69 @@ def mla_decode(q: torch.Tensor, c_kv: torch.Tensor, k_rope: torch.Tensor, cos: t
     return out
 
 
+def mla_decode_paged(q: torch.Tensor, c_kv: torch.Tensor, k_rope: torch.Tensor, block_tables: torch.Tensor,
+                     cos: torch.Tensor, sin: torch.Tensor, context_lens: torch.Tensor, max_context: int, scale: float,
+                     row_seq: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Latent-space MLA attention over a block cache (mi355_mla_decode_paged).
+
+    c_kv [blocks, block_size, R] and k_rope [blocks, block_size, P] -- typically the two column
+    ranges pool[..., :R] and pool[..., R:] of one pool [blocks, block_size, R + P] -- in q's dtype;
+    block_tables [sequences, max_blocks] int32: token t of sequence s sits in block
+    block_tables[s][t // block_size], row t % block_size.  Everything else as in mla_decode, whose
+    result it equals bit for bit on the same rows.  block_size must be a power of two."""
+    dev = require_device(q, c_kv, k_rope, block_tables, cos, sin, context_lens, row_seq)
+    lib = _lib.load()
+    if q.dim() != 3 or c_kv.dim() != 3 or k_rope.dim() != 3:
+        raise ValueError("q [rows,H,R+P], c_kv [blocks,block_size,R], k_rope [blocks,block_size,P] expected")
+    rows, H, DQ = q.shape
+    R, P = c_kv.shape[2], k_rope.shape[2]
+    if DQ != R + P:
+        raise ValueError(f"q last dim {DQ} != kv_lora_rank {R} + rope dim {P}")
+    if c_kv.dtype != q.dtype or k_rope.dtype != q.dtype:
+        raise TypeError("q, c_kv and k_rope must share one dtype")
+    if tuple(k_rope.shape[:2]) != tuple(c_kv.shape[:2]):
+        raise ValueError("c_kv and k_rope must hold the same [blocks, block_size] rows")
+    if q.stride(2) != 1 or q.stride(1) != DQ:
+        q = q.contiguous()
+    if c_kv.stride(2) != 1 or k_rope.stride(2) != 1:
+        raise ValueError("cache rows must be contiguous in their last dimension (views of a pool are fine)")
+    num_blocks, block_size = c_kv.shape[0], c_kv.shape[1]
+    cos = cos.to(torch.float32).contiguous()
+    sin = sin.to(torch.float32).contiguous()
+    if cos.shape[-1] != P or tuple(sin.shape) != tuple(cos.shape):
+        raise ValueError("cos / sin must be [table_len, rope_dim]")
+    if block_tables.dtype != torch.int32 or context_lens.dtype != torch.int32 or \
+            (row_seq is not None and row_seq.dtype != torch.int32):
+        raise TypeError("block_tables / context_lens / row_seq must be int32")
+    block_tables = block_tables.contiguous()
+    if block_tables.dim() != 2:
+        raise ValueError("block_tables must be [sequences, max_blocks]")
+    if context_lens.numel() != rows or (row_seq is not None and row_seq.numel() != rows):
+        raise ValueError("context_lens / row_seq must have one entry per query row")
+    if row_seq is None and rows > block_tables.shape[0]:
+        raise ValueError(f"{rows} query rows but {block_tables.shape[0]} block-table rows (pass row_seq to share them)")
+    max_context = min(int(max_context), block_tables.shape[1] * block_size)
+    if max_context > cos.shape[0]:
+        raise ValueError(f"max_context {max_context} exceeds the cos/sin table ({cos.shape[0]})")
+    out = torch.empty((rows, H, R), dtype=torch.float32, device=dev)
+    code = dtype_code(q)
+    with _on(dev):
+        stream = _stream(dev)
+        need = lib.mi355_mla_decode_workspace_bytes(rows, H, R, P, max_context, code)
+        ws, ws_bytes = _workspace(dev, need, stream)
+        rc = lib.mi355_mla_decode_paged(
+            out.data_ptr(), q.data_ptr(), _stride(q, 0),
+            c_kv.data_ptr(), _stride(c_kv, 0), _stride(c_kv, 1),
+            k_rope.data_ptr(), _stride(k_rope, 0), _stride(k_rope, 1),
+            block_tables.data_ptr(), block_size, block_tables.shape[1], num_blocks,
+            cos.data_ptr(), sin.data_ptr(), cos.shape[0], context_lens.contiguous().data_ptr(),
+            row_seq.contiguous().data_ptr() if row_seq is not None else None,
+            rows, H, R, P, max_context, float(scale), code,
+            ws.data_ptr() if ws is not None else None, ws_bytes, stream)
+    _lib.check(rc, 'mi355_mla_decode_paged')
+    return out
+
+
 def _head_rows(t: torch.Tensor) -> torch.Tensor:
     """[T, H, D] with contiguous head rows packed D apart (any token stride)."""
     if t.dim() != 3 or t.stride(2) != 1 or (t.shape[1] != 1 and t.stride(1) != t.shape[2]):

@@ -4,6 +4,10 @@
     rotate_half, apply_rotary_emb, RotaryEmbedding, MLAKVCache,
     MultiHeadLatentAttention, compare_kv_cache_size
 
+plus, with no counterpart in the reference, a block cache for the latent rows (PagedMLAKVCache)
+and MultiHeadLatentAttention.forward_paged, which attends through block tables
+(mi355_mla_decode_paged).
+
 The projections, norms and RoPE of the *query* are torch ops.  The attention itself never
 expands the cached latent rows to per-head K/V as the reference does
 (04_mla/mini_mla.py:245-248): the key up-projection is folded into the query and the value
@@ -89,6 +93,76 @@ class MLAKVCache:
             dst[:, :self.kv_lora_rank] = c_kv[b]
             dst[:, self.kv_lora_rank:] = k_rope[b]
         self.seq_lens[:batch] += new_tokens
+
+
+class PagedMLAKVCache:
+    """Block cache of the latent rows: pool [layers, num_blocks, block_size, kv_lora_rank + rope_dim]
+    and one block table per sequence, with the blocks handed out by the engine's BlockAllocator
+    (mini_vllm.BlockAllocator: the same ids, free list and hash map the K/V caches of
+    paged_attention use), so that latent caches share the pool management -- and prefix sharing --
+    of the paged K/V path.  The reference keeps dense per-sequence tensors (MLAKVCache above,
+    04_mla/mini_mla.py:79-132); this class has no counterpart there.  block_size: a power of two."""
+
+    def __init__(self, num_blocks: int, block_size: int, num_layers: int, kv_lora_rank: int,
+                 qk_rope_head_dim: int, device, dtype: torch.dtype = torch.bfloat16, allocator=None):
+        if block_size <= 0 or block_size & (block_size - 1):
+            raise ValueError(f"block_size {block_size} is not a power of two")
+        if allocator is None:
+            from mini_vllm import BlockAllocator
+            allocator = BlockAllocator(num_blocks, block_size)
+        self.allocator = allocator
+        self.block_size = block_size
+        self.kv_lora_rank = kv_lora_rank
+        self.qk_rope_head_dim = qk_rope_head_dim
+        self.pool = torch.zeros(num_layers, num_blocks, block_size, kv_lora_rank + qk_rope_head_dim,
+                                device=device, dtype=dtype)
+        self.block_tables: dict = {}     # sequence id -> list of block ids
+        self.seq_lens: dict = {}         # sequence id -> tokens held (of the layer written last)
+        self._layer_lens: dict = {}      # (sequence id, layer) -> tokens held
+
+    def _slots(self, seq_id, first: int, count: int) -> torch.Tensor:
+        table = self.block_tables.setdefault(seq_id, [])
+        bs = self.block_size
+        while len(table) * bs < first + count:
+            blk = self.allocator.allocate()
+            if blk is None:
+                raise RuntimeError(f"OOM: no free latent-cache block for sequence {seq_id!r}")
+            table.append(blk)
+        pos = torch.arange(first, first + count)
+        return torch.tensor(table, dtype=torch.long)[pos // bs] * bs + pos % bs
+
+    def append(self, seq_id, layer_id: int, c_kv: torch.Tensor, k_rope: torch.Tensor) -> int:
+        """Stores T new rows of one sequence ([T, kv_lora_rank], [T, rope_dim]) behind the rows the
+        layer already holds; returns the sequence's length in that layer afterwards."""
+        first = self._layer_lens.get((seq_id, layer_id), 0)
+        count = c_kv.shape[0]
+        slots = self._slots(seq_id, first, count).to(self.pool.device)
+        rows = torch.cat((c_kv, k_rope), dim=-1).to(device=self.pool.device, dtype=self.pool.dtype)
+        self.pool[layer_id].view(-1, rows.shape[-1])[slots] = rows
+        self._layer_lens[(seq_id, layer_id)] = first + count
+        self.seq_lens[seq_id] = first + count
+        return first + count
+
+    def length(self, seq_id, layer_id: int) -> int:
+        return self._layer_lens.get((seq_id, layer_id), 0)
+
+    def tables(self, seq_ids) -> torch.Tensor:
+        """int32 [len(seq_ids), max_blocks] on the pool's device, rows padded with block 0."""
+        width = max(1, max(len(self.block_tables.get(s, ())) for s in seq_ids))
+        rows = [list(self.block_tables.get(s, ())) + [0] * (width - len(self.block_tables.get(s, ()))) for s in seq_ids]
+        return torch.tensor(rows, dtype=torch.int32).to(self.pool.device)
+
+    def views(self, layer_id: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(c_kv [blocks, block_size, R], k_rope [blocks, block_size, P]) column views of the layer's pool."""
+        layer = self.pool[layer_id]
+        return layer[..., :self.kv_lora_rank], layer[..., self.kv_lora_rank:]
+
+    def free(self, seq_id) -> None:
+        for blk in self.block_tables.pop(seq_id, ()):
+            self.allocator.free(blk)
+        self.seq_lens.pop(seq_id, None)
+        for key in [k for k in self._layer_lens if k[0] == seq_id]:
+            del self._layer_lens[key]
 
 
 def _compute_device(t: torch.Tensor) -> torch.device:
@@ -206,6 +280,42 @@ class MultiHeadLatentAttention(nn.Module):
 
         out = torch.einsum('bthl,hvl->bthv', o_lat.view(B, T, H, lora), w_kv[:, nope:])
         return self.o_proj(out.reshape(B, T, H * vd)), new_c_kv, new_k_rope
+
+
+    @torch.no_grad()
+    def forward_paged(self, hidden_states: torch.Tensor, positions: torch.Tensor, cache: PagedMLAKVCache,
+                      layer_id: int, seq_ids) -> torch.Tensor:
+        """forward() over a block cache (inference only): the T new latent rows of every sequence
+        in `seq_ids` (one per batch row) are appended to `cache`, and the heads attend to the
+        sequence's cached rows through its block table (mi355_mla_decode_paged) -- no dense
+        past_c_kv / past_k_rope tensors are built.  hidden_states [B, T, hidden], positions [B, T]
+        -> output [B, T, hidden]; equals forward() fed with the same rows as dense tensors."""
+        B, T, _ = hidden_states.shape
+        H, nope, rope, lora, vd = (self.num_heads, self.qk_nope_head_dim, self.qk_rope_head_dim,
+                                   self.kv_lora_rank, self.v_head_dim)
+        q = self.q_b_proj(self.q_a_layernorm(self.q_a_proj(hidden_states))).view(B, T, H, nope + rope)
+        compressed = self.kv_a_proj_with_mqa(hidden_states)
+        new_c_kv = self.kv_a_layernorm(compressed[..., :lora])
+        new_k_rope = compressed[..., lora:]
+        lens = [cache.append(seq_ids[b], layer_id, new_c_kv[b], new_k_rope[b]) for b in range(B)]
+        S = max(lens)
+        cos, sin = self.rotary_emb(int(max(int(positions.max().item()) + 1, S)))
+        flat = positions.reshape(-1)
+        q_rope = q[..., nope:] * cos[flat].view(B, T, 1, rope) + rotate_half(q[..., nope:]) * sin[flat].view(B, T, 1, rope)
+        w_kv = self.kv_b_proj.weight.view(H, nope + vd, lora)
+        q_lat = torch.einsum('bthn,hnl->bthl', q[..., :nope], w_kv[:, :nope])
+        q_cat = torch.cat((q_lat, q_rope), dim=-1).reshape(B * T, H, lora + rope)
+        dev = cache.pool.device
+        kdtype = cache.pool.dtype
+        # query token i of sequence b sees cached tokens 0 .. len_b - T + i
+        context = torch.tensor([n - T + i + 1 for n in lens for i in range(T)], dtype=torch.int32, device=dev)
+        row_seq = torch.arange(B, dtype=torch.int32, device=dev).repeat_interleave(T)
+        c_view, r_view = cache.views(layer_id)
+        o_lat = ops.mla_decode_paged(q_cat.to(device=dev, dtype=kdtype), c_view, r_view, cache.tables(seq_ids),
+                                     cos[:S].to(dev), sin[:S].to(dev), context, S, self.scale, row_seq=row_seq)
+        o_lat = o_lat.to(device=hidden_states.device, dtype=hidden_states.dtype)
+        out = torch.einsum('bthl,hvl->bthv', o_lat.view(B, T, H, lora), w_kv[:, nope:])
+        return self.o_proj(out.reshape(B, T, H * vd))
 
 
 def compare_kv_cache_size(num_heads: int = 32, head_dim: int = 128, kv_lora_rank: int = 512,
