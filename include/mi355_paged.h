@@ -112,7 +112,8 @@ size_t mi355_paged_decode_workspace_bytes(int32_t B, int32_t Hq, int32_t Hkv, in
  * MI355_STATIC_SCRATCH_BYTES that is part of the library's device image, so every GPU the
  * library runs on holds that much memory until the process ends.  The call performs no
  * hipMalloc / hipFree; its first split call on a device looks the array's address up once
- * (hipGetSymbolAddress), with that device current.
+ * (hipGetSymbolAddress), with that device current: make that first call outside a capture (one
+ * eager call per device), later calls may be captured and replayed.
  *   - A shape whose partials (mi355_paged_decode_workspace_bytes) exceed
  *     MI355_STATIC_SCRATCH_BYTES is rejected with MI355_EWORKSPACE before any launch.
  *   - All calls on one GPU share the array: calls whose kernels may overlap on that GPU

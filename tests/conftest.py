@@ -43,13 +43,34 @@ def _start_dp_job():
 
 
 def pytest_configure(config):
-    global DP_JOB
     config.addinivalue_line('markers', 'gpu: needs a HIP device (MI355X)')
-    markexpr = (config.getoption('markexpr', '') or '').strip()
-    if markexpr == 'gpu' and DP_JOB is None:
+
+
+@pytest.hookimpl(trylast=True)
+def pytest_collection_modifyitems(config, items):
+    """Starts the two-rank job only when its test is among the selected ones (after -m / -k have
+    deselected), and before any test -- i.e. any GPU call -- has run in this process."""
+    global DP_JOB
+    wanted = any(item.fspath.basename == 'test_zy_dp_engine_gpu.py' for item in items)
+    if wanted and DP_JOB is None:
         import torch
         if torch.cuda.device_count() > 0:
             DP_JOB = _start_dp_job()
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """The job's processes do not outlive the session (a session that stopped before the test that
+    waits for them, -x or an interrupt, would leave them behind)."""
+    if DP_JOB is None:
+        return
+    proc = DP_JOB[0]
+    if proc.poll() is None:
+        proc.terminate()
+        try:
+            proc.wait(timeout=20)
+        except Exception:
+            proc.kill()
+            proc.wait()
 
 
 def load_npz(name):

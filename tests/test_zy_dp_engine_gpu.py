@@ -1,7 +1,7 @@
 """Engine-level data parallelism on the device: two ranks sharing the one GPU (gloo) must give
 every request the tokens a single engine gives it on the whole batch, bit for bit under greedy
-sampling.  The two-rank job is started by conftest.py when the session begins -- child processes
-are started before this process has made any GPU call -- and only its result is read here."""
+sampling.  The two-rank job is started by conftest.py once collection has selected this test -- child
+processes are started before this process has made any GPU call -- and only its result is read here."""
 import json
 import os
 
@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 def test_engine_data_parallel_two_ranks_equal_single_engine(device):
     job = conftest.DP_JOB
-    assert job is not None, "conftest did not start the two-rank job (needs `-m gpu` and a visible GPU)"
+    assert job is not None, "conftest did not start the two-rank job (needs a visible GPU)"
     proc, out_dir = job
     try:
         rc = proc.wait(timeout=240)

@@ -123,3 +123,59 @@ def test_static_scratch_rejects_shapes_beyond_the_array(device):
     msg = lib.mi355_last_error().decode()
     assert 'built-in scratch' in msg and str(need) in msg, msg
     torch.cuda.synchronize()
+
+
+def test_static_scratch_decode_under_graph_capture(device):
+    """The call is made for code under HIP graph capture: captured (after one eager call on the device,
+    which looks the scratch array's address up) and replayed on changed inputs, a split shape gives
+    what mi355_paged_decode gives on those inputs; the driver's free-memory figure does not move
+    around the eager call nor around the replays (a hipMalloc inside the library would show there,
+    not in torch's allocator statistics)."""
+    from mi355_paged import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(77)
+    with torch.cuda.device(device):
+        pr = _problem(rng, device, torch.bfloat16, B=3, Hq=8, Hkv=8, D=64, BS=16, ctx=[6000, 8192, 37])
+        need = lib.mi355_paged_decode_workspace_bytes(pr['B'], pr['Hq'], pr['Hkv'], pr['D'], pr['BS'], pr['max_ctx'], 1)
+        assert need > 0
+        ws = torch.empty(need, dtype=torch.uint8, device=device)
+        ref = torch.empty((pr['B'], pr['Hq'], pr['D']), dtype=torch.bfloat16, device=device)
+        got = torch.full_like(ref, float('nan'))
+        q2 = (pr['q'].float() * -0.5 + 0.25).to(torch.bfloat16)          # the replay's inputs, allocated beforehand
+        ctx2 = torch.tensor([8000, 100, 8192], dtype=torch.int32, device=device)
+        side = torch.cuda.Stream(device=device)
+        with torch.cuda.stream(side):
+            # the eager call a device needs before captures: the library's device image (its code and the
+            # scratch array with it) is loaded by the first call, and the array's address is looked up
+            rc = lib.mi355_paged_decode_static(*_args(pr, got), side.cuda_stream)
+            assert rc == 0, lib.mi355_last_error()
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info(device)[0]
+        with torch.cuda.stream(side):
+            rc = lib.mi355_paged_decode_static(*_args(pr, got), side.cuda_stream)
+            assert rc == 0, lib.mi355_last_error()
+        side.synchronize()
+        assert torch.cuda.mem_get_info(device)[0] == free0          # the call took no device memory
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            rc = lib.mi355_paged_decode_static(*_args(pr, got), torch.cuda.current_stream(device).cuda_stream)
+            assert rc == 0, lib.mi355_last_error()
+        inputs = ((pr['q'].clone(), pr['ctx'].clone()), (q2, ctx2))
+        outs = [torch.empty_like(got) for _ in inputs]
+        graph.replay()                                              # (the first replay uploads the graph)
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info(device)[0]                  # (capturing is the framework's business)
+        for (q_new, ctx_new), keep in zip(inputs, outs):
+            pr['q'].copy_(q_new)
+            pr['ctx'].copy_(ctx_new)
+            graph.replay()
+            keep.copy_(got)
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info(device)[0] == free0
+        for (q_new, ctx_new), keep in zip(inputs, outs):
+            pr['q'].copy_(q_new)
+            pr['ctx'].copy_(ctx_new)
+            rc = lib.mi355_paged_decode(*_args(pr, ref), ws.data_ptr(), need, torch.cuda.current_stream(device).cuda_stream)
+            assert rc == 0, lib.mi355_last_error()
+            torch.cuda.synchronize()
+            assert torch.equal(keep.view(torch.uint8), ref.view(torch.uint8))

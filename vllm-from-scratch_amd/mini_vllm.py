@@ -991,7 +991,10 @@ class MiniTransformer(nn.Module):
         addresses; it stays valid under in-place edits of the values (a replay reads memory as it
         is then) and must be dropped when any tensor is replaced by another."""
         for layer in self.layers:
-            if layer.ffn.gate.weight.is_cuda and not layer.ffn.gate.weight.requires_grad:
+            # (whether or not the parameters ask for gradients: the engine's steps run without autograd
+            # and would fuse at their first forward anyway -- after this key was taken, so that the
+            # first captured step would be dropped as stale and captured again)
+            if layer.ffn.gate.weight.is_cuda:
                 layer.ffn._gate_up_weight()          # fuses, or re-fuses if a half was replaced (new addresses)
         slots = self.__dict__.get('_tensor_slots')
         if slots is None:     # (holding dict, name) of every parameter and buffer: walked once, read every step
