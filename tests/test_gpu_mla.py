@@ -394,7 +394,8 @@ def _scatter_into_blocks(rng, c_kv, k_rope, block_size, spare=3):
     # seqs, H, R, P, max_ctx, block_size
     (3, 4, 32, 8, 40, 4), (2, 8, 64, 16, 100, 16), (2, 16, 128, 32, 333, 16), (2, 16, 512, 64, 700, 16),
     (1, 20, 256, 64, 50, 8), (3, 17, 512, 64, 95, 32), (2, 32, 512, 64, 700, 16), (1, 64, 512, 64, 3000, 16),
-    (2, 16, 512, 64, 130, 1), (1, 16, 512, 64, 9000, 64),
+    (2, 16, 512, 64, 130, 1), (1, 16, 512, 64, 9000, 64), (3, 16, 512, 64, 333, 8), (2, 48, 512, 64, 1500, 128),
+    (2, 16, 512, 64, 97, 4), (2, 16, 512, 32, 200, 16),
 ])
 def test_mla_decode_paged_equals_the_dense_call(ops, device, shape, dtype):
     """A dense latent cache scattered into random blocks of a pool (every other pool row NaN): the

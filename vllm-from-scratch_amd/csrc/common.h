@@ -39,6 +39,7 @@ enum Knob {
   kKnobDecodeFusedMerge,  // MI355_DECODE_FUSED_MERGE  most token splits the VALU decode kernel merges in its own launch (0: never)
   kKnobPagedBalanceWgs,   // MI355_PAGED_BALANCE_WGS   workgroups a decode launch spreads its kv heads over for ragged batches (0: off)
   kKnobDpExchangeProbe,   // MI355_DP_EXCHANGE_PROBE   measurement only, bit mask: 1 no collective, 2 no completion event, 4 no watcher
+  kKnobMlaRowGroups,      // MI355_MLA_ROW_GROUPS      1: paged rank-512 MLA tiles staged as 8 consecutive rows per wave
   kKnobCount
 };
 int knob(Knob k);

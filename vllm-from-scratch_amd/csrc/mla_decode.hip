@@ -59,24 +59,58 @@ struct MlaParams {
   int bs_shift = 0, bs_mask = 0, max_blocks = 0, num_blocks = 0;
 };
 
+// Addressing modes of the kernels below (template parameter PAGED).
+constexpr int kDense = 0;        // rows of one sequence at a fixed stride from the sequence's base
+constexpr int kPaged = 1;        // rows in blocks named by a block table, any power-of-two block size
+constexpr int kPagedGroups = 2;  // ... blocks of >= 8 tokens, kv_lora_rank 512, rope slot 64: see GroupAt
+constexpr bool is_paged(int mode) { return mode == kPaged || mode == kPagedGroups; }
+constexpr bool is_grouped(int mode) { return mode == kPagedGroups; }
+
 // Element offset of token `tok`'s row from the cache base: dense rows of one sequence (the base
 // already points at the sequence), or a row of the block the sequence's table names.
-template <bool PAGED>
+template <int PAGED>
 struct RowAt {
   const MlaParams& p;
   const int32_t* bt_row;
-  __device__ __forceinline__ RowAt(const MlaParams& p_, int seq) : p(p_), bt_row(PAGED ? p_.bt + (int64_t)seq * p_.max_blocks : nullptr) {}
+  __device__ __forceinline__ RowAt(const MlaParams& p_, int seq) : p(p_), bt_row(is_paged(PAGED) ? p_.bt + (int64_t)seq * p_.max_blocks : nullptr) {}
   __device__ __forceinline__ int block(int tok) const {
     return min(max(bt_row[tok >> p.bs_shift], 0), p.num_blocks - 1);
   }
   __device__ __forceinline__ int64_t ckv(int tok) const {
-    if constexpr (PAGED) return (int64_t)block(tok) * p.ckv_stride_blk + (int64_t)(tok & p.bs_mask) * p.ckv_stride_tok;
+    if constexpr (is_paged(PAGED)) return (int64_t)block(tok) * p.ckv_stride_blk + (int64_t)(tok & p.bs_mask) * p.ckv_stride_tok;
     else return (int64_t)tok * p.ckv_stride_tok;
   }
   __device__ __forceinline__ int64_t krope(int tok) const {
-    if constexpr (PAGED) return (int64_t)block(tok) * p.krope_stride_blk + (int64_t)(tok & p.bs_mask) * p.krope_stride_tok;
+    if constexpr (is_paged(PAGED)) return (int64_t)block(tok) * p.krope_stride_blk + (int64_t)(tok & p.bs_mask) * p.krope_stride_tok;
     else return (int64_t)tok * p.krope_stride_tok;
   }
+};
+
+// kPagedGroups: each wave of the four-wave kernels stages 8 CONSECUTIVE rows of a 32-token tile
+// (one row = one 64-lane load), and with blocks of >= 8 tokens those 8 rows lie in one block.
+// The table lookup, the clamp and the 64-bit address of the group's first row are then computed
+// once per wave and tile on the scalar unit, and a row adds a 32-bit offset.  (With one wave per SIMD nothing hides
+// address arithmetic: per-row addressing, ~15 scalar instructions for each of 8 rows, measured
+// +15 % on the whole kernel at 256 rows x 4096 tokens; grouped: +3 %.)  Dense caches keep the
+// other row order (wave w stages rows w, w + 4, ...: the four waves' loads of one moment cover
+// 4 adjacent rows), which measures 0.5 % (16 heads) to 3 % (128 heads) faster than groups there.
+// Rows past the sequence's end re-read its last row, as in the other modes.
+struct GroupAt {
+  const char* ckv_base = nullptr;
+  const char* krope_base = nullptr;
+  int n_last = 0;   // rows of the group before its last valid one
+  __device__ __forceinline__ GroupAt(const MlaParams& p, int mode, const char* ckv, const char* krope, int ids, int t0,
+                                     int t_end, int wave_u) {
+    if (!is_grouped(mode)) return;
+    const int last = t_end - 1;
+    const int gs = min(t0 + 8 * wave_u, last & ~7);      // first row of the group, pulled back to the last live group
+    n_last = min(last - gs, 7);
+    const int id = min(max(__builtin_amdgcn_readlane(ids, (gs >> p.bs_shift) - (t0 >> p.bs_shift)), 0), p.num_blocks - 1);
+    const int r0 = gs & p.bs_mask;
+    ckv_base = ckv + ((int64_t)id * p.ckv_stride_blk + (int64_t)r0 * p.ckv_stride_tok) * 2;
+    krope_base = krope + ((int64_t)id * p.krope_stride_blk + (int64_t)r0 * p.krope_stride_tok) * 2;
+  }
+  __device__ __forceinline__ int row_bytes(int i, int stride_tok) const { return min(i, n_last) * (stride_tok * 2); }
 };
 
 template <class Tag>
@@ -109,7 +143,7 @@ struct Mma16<F16> {
   }
 };
 
-template <class Tag, int R, int PP, bool PAGED = false>
+template <class Tag, int R, int PP, int PAGED = kDense>
 __global__ void __launch_bounds__(kWave) mla_decode_kernel(const MlaParams p) {
   constexpr int DK = R + PP;              // key dims incl. zero padding of the rope part
   constexpr int KS = DK / 32;             // MFMA k-steps of the score product
@@ -147,8 +181,8 @@ __global__ void __launch_bounds__(kWave) mla_decode_kernel(const MlaParams p) {
   for (int ot = 0; ot < OT; ++ot) o[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -1.0e30f, l_run = 0.f;
 
-  const char* ckv = static_cast<const char*>(p.ckv) + (PAGED ? 0 : (int64_t)seq * p.ckv_stride_seq * 2);
-  const char* krope = static_cast<const char*>(p.krope) + (PAGED ? 0 : (int64_t)seq * p.krope_stride_seq * 2);
+  const char* ckv = static_cast<const char*>(p.ckv) + (is_paged(PAGED) ? 0 : (int64_t)seq * p.ckv_stride_seq * 2);
+  const char* krope = static_cast<const char*>(p.krope) + (is_paged(PAGED) ? 0 : (int64_t)seq * p.krope_stride_seq * 2);
   const RowAt<PAGED> at(p, seq);
   const int half = p.P >> 1;
 
@@ -258,7 +292,7 @@ __global__ void __launch_bounds__(kWave) mla_decode_kernel(const MlaParams p) {
 // of the query fragments in registers and reads a quarter of the tile; each wave then owns a
 // quarter of the latent output dims for all 32 tokens.  Registers and LDS stay low enough for
 // 2 workgroups (8 waves) per CU.
-template <class Tag, int R, int PP, bool PAGED = false>
+template <class Tag, int R, int PP, int PAGED = kDense>
 __global__ void __launch_bounds__(256, 2) mla_decode_kernel_w4(const MlaParams p) {
   constexpr int DK = R + PP;
   constexpr int KS = DK / 32;
@@ -307,8 +341,8 @@ __global__ void __launch_bounds__(256, 2) mla_decode_kernel_w4(const MlaParams p
   for (int i = 0; i < OTW; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -1.0e30f, l_run = 0.f;
 
-  const char* ckv = static_cast<const char*>(p.ckv) + (PAGED ? 0 : (int64_t)seq * p.ckv_stride_seq * 2);
-  const char* krope = static_cast<const char*>(p.krope) + (PAGED ? 0 : (int64_t)seq * p.krope_stride_seq * 2);
+  const char* ckv = static_cast<const char*>(p.ckv) + (is_paged(PAGED) ? 0 : (int64_t)seq * p.ckv_stride_seq * 2);
+  const char* krope = static_cast<const char*>(p.krope) + (is_paged(PAGED) ? 0 : (int64_t)seq * p.krope_stride_seq * 2);
   const RowAt<PAGED> at(p, seq);
   const int half = p.P >> 1;
   // rope rotation: thread = (token of the tile, group of 4 consecutive pairs), so that the 8 lanes
@@ -330,15 +364,18 @@ __global__ void __launch_bounds__(256, 2) mla_decode_kernel_w4(const MlaParams p
   // steady state waits for a table entry (a dependent table read in the address path would sit
   // behind the prefetched tiles in the in-order load queue and drain it).
   auto load_ids = [&](int t0) {
-    if constexpr (PAGED) return at.bt_row[min((t0 >> p.bs_shift) + (lane & 31), p.max_blocks - 1)];
+    if constexpr (is_paged(PAGED)) return at.bt_row[min((t0 >> p.bs_shift) + (lane & 31), p.max_blocks - 1)];
     else return 0;
   };
   auto issue_loads = [&](int t0, u32x4 (&stage)[NLOAD], int ids) {
     const int blk0 = t0 >> p.bs_shift;
+    const GroupAt grp(p, PAGED, ckv, krope, ids, t0, t_end, __builtin_amdgcn_readfirstlane(wave));
 #pragma unroll
     for (int i = 0; i < NCKV; ++i) {
       const int tok = min(t0 + crow + RSTEP * i, t_end - 1);   // rows past the end re-read the last one (masked later)
-      if constexpr (PAGED && CCH % kWave == 0) {
+      if constexpr (is_grouped(PAGED)) {
+        stage[i] = load16<true>(grp.ckv_base + (uint32_t)(grp.row_bytes(i, cstride) + ccol * 16));
+      } else if constexpr (is_paged(PAGED) && CCH % kWave == 0) {
         // a wave's load is one token row (kv_lora_rank 512: 64 lanes x 16 bytes): the row, its block id
         // and the row's base address are wave-uniform, i.e. scalar work, and the load takes the
         // scalar base plus the lane's fixed column offset
@@ -346,7 +383,7 @@ __global__ void __launch_bounds__(256, 2) mla_decode_kernel_w4(const MlaParams p
         const int id = min(max(__builtin_amdgcn_readlane(ids, (tok_u >> p.bs_shift) - blk0), 0), p.num_blocks - 1);
         const char* rowp = ckv + ((int64_t)id * p.ckv_stride_blk + (int64_t)(tok_u & p.bs_mask) * cstride) * 2;
         stage[i] = load16<true>(rowp + (uint32_t)(ccol * 16));
-      } else if constexpr (PAGED) {
+      } else if constexpr (is_paged(PAGED)) {
         const int id = min(max(__shfl(ids, (tok >> p.bs_shift) - blk0), 0), p.num_blocks - 1);
         stage[i] = load16<true>(ckv + ((int64_t)id * p.ckv_stride_blk + (int64_t)((tok & p.bs_mask) * cstride + ccol * 8)) * 2);
       } else {
@@ -357,7 +394,10 @@ __global__ void __launch_bounds__(256, 2) mla_decode_kernel_w4(const MlaParams p
     // unconditional (address clamped into the row) so the compiler can count outstanding loads
     // exactly; lanes beyond the rope width are zeroed when the stage is written to LDS
     const int tok = min(t0 + min(krow, kTok2 - 1), t_end - 1);
-    if constexpr (PAGED) {
+    if constexpr (is_grouped(PAGED)) {
+      // (rope slot 64: thread tid stages chunk tid % 8 of row tid / 8, a row of its own wave's group)
+      stage[NCKV] = load16<true>(grp.krope_base + (uint32_t)(min(lane >> 3, grp.n_last) * (rstride * 2) + kcol_ld * 16));
+    } else if constexpr (is_paged(PAGED)) {
       const int id = min(max(__shfl(ids, (tok >> p.bs_shift) - blk0), 0), p.num_blocks - 1);
       stage[NCKV] = load16<true>(krope + ((int64_t)id * p.krope_stride_blk + (int64_t)((tok & p.bs_mask) * rstride + kcol_ld * 8)) * 2);
     } else {
@@ -387,7 +427,7 @@ __global__ void __launch_bounds__(256, 2) mla_decode_kernel_w4(const MlaParams p
     unsigned char* tile = tiles[t & 1];
 #pragma unroll
     for (int i = 0; i < NCKV; ++i)
-      *reinterpret_cast<u32x4*>(tile + (crow + RSTEP * i) * ROWB + ccol * 16) = stage[i];
+      *reinterpret_cast<u32x4*>(tile + (is_grouped(PAGED) ? crow * NCKV + i : crow + RSTEP * i) * ROWB + ccol * 16) = stage[i];
     if (krow < kTok2)
       *reinterpret_cast<u32x4*>(tile + krow * ROWB + R * 2 + kcol * 16) = k_live ? stage[NCKV] : u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
@@ -535,7 +575,7 @@ __global__ void __launch_bounds__(256, 2) mla_decode_kernel_w4(const MlaParams p
 // (one wave per SIMD) per CU, with the two-tile register prefetch covering the memory latency.
 // Per 32-token tile a wave issues 2 x KS + R / 16 matrix instructions (68 at R = 512, about a
 // third of the time the tile's 36 KiB take to arrive at the CU's share of HBM bandwidth).
-template <class Tag, int R, int PP, bool PAGED = false>
+template <class Tag, int R, int PP, int PAGED = kDense>
 __global__ void __launch_bounds__(256) mla_decode_kernel_mh(const MlaParams p) {
   constexpr int DK = R + PP;
   constexpr int KS = DK / 32;
@@ -584,8 +624,8 @@ __global__ void __launch_bounds__(256) mla_decode_kernel_mh(const MlaParams p) {
   for (int i = 0; i < OT; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -1.0e30f, l_run = 0.f;
 
-  const char* ckv = static_cast<const char*>(p.ckv) + (PAGED ? 0 : (int64_t)seq * p.ckv_stride_seq * 2);
-  const char* krope = static_cast<const char*>(p.krope) + (PAGED ? 0 : (int64_t)seq * p.krope_stride_seq * 2);
+  const char* ckv = static_cast<const char*>(p.ckv) + (is_paged(PAGED) ? 0 : (int64_t)seq * p.ckv_stride_seq * 2);
+  const char* krope = static_cast<const char*>(p.krope) + (is_paged(PAGED) ? 0 : (int64_t)seq * p.krope_stride_seq * 2);
   const RowAt<PAGED> at(p, seq);
   const int half = p.P >> 1;
   // rope rotation: thread = (token of the tile, group of 4 consecutive pairs), so that the 8 lanes
@@ -607,15 +647,18 @@ __global__ void __launch_bounds__(256) mla_decode_kernel_mh(const MlaParams p) {
   // steady state waits for a table entry (a dependent table read in the address path would sit
   // behind the prefetched tiles in the in-order load queue and drain it).
   auto load_ids = [&](int t0) {
-    if constexpr (PAGED) return at.bt_row[min((t0 >> p.bs_shift) + (lane & 31), p.max_blocks - 1)];
+    if constexpr (is_paged(PAGED)) return at.bt_row[min((t0 >> p.bs_shift) + (lane & 31), p.max_blocks - 1)];
     else return 0;
   };
   auto issue_loads = [&](int t0, u32x4 (&stage)[NLOAD], int ids) {
     const int blk0 = t0 >> p.bs_shift;
+    const GroupAt grp(p, PAGED, ckv, krope, ids, t0, t_end, __builtin_amdgcn_readfirstlane(wave));
 #pragma unroll
     for (int i = 0; i < NCKV; ++i) {
       const int tok = min(t0 + crow + RSTEP * i, t_end - 1);   // rows past the end re-read the last one (masked later)
-      if constexpr (PAGED && CCH % kWave == 0) {
+      if constexpr (is_grouped(PAGED)) {
+        stage[i] = load16<true>(grp.ckv_base + (uint32_t)(grp.row_bytes(i, cstride) + ccol * 16));
+      } else if constexpr (is_paged(PAGED) && CCH % kWave == 0) {
         // a wave's load is one token row (kv_lora_rank 512: 64 lanes x 16 bytes): the row, its block id
         // and the row's base address are wave-uniform, i.e. scalar work, and the load takes the
         // scalar base plus the lane's fixed column offset
@@ -623,7 +666,7 @@ __global__ void __launch_bounds__(256) mla_decode_kernel_mh(const MlaParams p) {
         const int id = min(max(__builtin_amdgcn_readlane(ids, (tok_u >> p.bs_shift) - blk0), 0), p.num_blocks - 1);
         const char* rowp = ckv + ((int64_t)id * p.ckv_stride_blk + (int64_t)(tok_u & p.bs_mask) * cstride) * 2;
         stage[i] = load16<true>(rowp + (uint32_t)(ccol * 16));
-      } else if constexpr (PAGED) {
+      } else if constexpr (is_paged(PAGED)) {
         const int id = min(max(__shfl(ids, (tok >> p.bs_shift) - blk0), 0), p.num_blocks - 1);
         stage[i] = load16<true>(ckv + ((int64_t)id * p.ckv_stride_blk + (int64_t)((tok & p.bs_mask) * cstride + ccol * 8)) * 2);
       } else {
@@ -634,7 +677,10 @@ __global__ void __launch_bounds__(256) mla_decode_kernel_mh(const MlaParams p) {
     // unconditional (address clamped into the row) so the compiler can count outstanding loads
     // exactly; lanes beyond the rope width are zeroed when the stage is written to LDS
     const int tok = min(t0 + min(krow, kTok2 - 1), t_end - 1);
-    if constexpr (PAGED) {
+    if constexpr (is_grouped(PAGED)) {
+      // (rope slot 64: thread tid stages chunk tid % 8 of row tid / 8, a row of its own wave's group)
+      stage[NCKV] = load16<true>(grp.krope_base + (uint32_t)(min(lane >> 3, grp.n_last) * (rstride * 2) + kcol_ld * 16));
+    } else if constexpr (is_paged(PAGED)) {
       const int id = min(max(__shfl(ids, (tok >> p.bs_shift) - blk0), 0), p.num_blocks - 1);
       stage[NCKV] = load16<true>(krope + ((int64_t)id * p.krope_stride_blk + (int64_t)((tok & p.bs_mask) * rstride + kcol_ld * 8)) * 2);
     } else {
@@ -664,7 +710,7 @@ __global__ void __launch_bounds__(256) mla_decode_kernel_mh(const MlaParams p) {
     unsigned char* tile = tiles[t & 1];
 #pragma unroll
     for (int i = 0; i < NCKV; ++i)
-      *reinterpret_cast<u32x4*>(tile + (crow + RSTEP * i) * ROWB + ccol * 16) = stage[i];
+      *reinterpret_cast<u32x4*>(tile + (is_grouped(PAGED) ? crow * NCKV + i : crow + RSTEP * i) * ROWB + ccol * 16) = stage[i];
     if (krow < kTok2)
       *reinterpret_cast<u32x4*>(tile + krow * ROWB + R * 2 + kcol * 16) = k_live ? stage[NCKV] : u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
@@ -889,9 +935,28 @@ int mla_plan(int rows, int H, int R, int P, int max_context, int dtype, MlaPlan*
   return 0;
 }
 
-template <class Tag, int R, bool PAGED>
+template <int R>
+int launch_tail(const MlaParams& p, hipStream_t s) {
+  if (int rc = check_launch("mla_decode_kernel")) return rc;
+  if (p.nsplit > 1) {
+    const int64_t threads = (int64_t)p.rows * p.H * (R / 4);
+    hipLaunchKernelGGL((mla_merge_kernel<R>), dim3((unsigned)ceil_div64(threads, 256)), dim3(256), 0, s, p);
+    return check_launch("mla_merge_kernel");
+  }
+  return 0;
+}
+
+template <class Tag, int R, int PAGED>
 int launch_r(const MlaParams& p, bool many, hipStream_t s) {
   const int64_t grid = (int64_t)p.rows * p.nsplit * p.n_ht;
+  if constexpr (R == 512 && PAGED == kPaged) {
+    if (p.P > 32 && p.bs_shift >= 3 && p.ckv_stride_tok < (1 << 26) && p.krope_stride_tok < (1 << 26) &&
+        knob(kKnobMlaRowGroups) != 0) {
+      if (many) hipLaunchKernelGGL((mla_decode_kernel_mh<Tag, R, 64, kPagedGroups>), dim3((unsigned)grid), dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((mla_decode_kernel_w4<Tag, R, 64, kPagedGroups>), dim3((unsigned)grid), dim3(256), 0, s, p);
+      return launch_tail<R>(p, s);
+    }
+  }
   if constexpr (R >= 128) {
     if (many) {
       if (p.P <= 32) hipLaunchKernelGGL((mla_decode_kernel_mh<Tag, R, 32, PAGED>), dim3((unsigned)grid), dim3(256), 0, s, p);
@@ -902,16 +967,10 @@ int launch_r(const MlaParams& p, bool many, hipStream_t s) {
     if (p.P <= 32) hipLaunchKernelGGL((mla_decode_kernel<Tag, R, 32, PAGED>), dim3((unsigned)grid), dim3(kWave), 0, s, p);
     else hipLaunchKernelGGL((mla_decode_kernel<Tag, R, 64, PAGED>), dim3((unsigned)grid), dim3(kWave), 0, s, p);
   }
-  if (int rc = check_launch("mla_decode_kernel")) return rc;
-  if (p.nsplit > 1) {
-    const int64_t threads = (int64_t)p.rows * p.H * (R / 4);
-    hipLaunchKernelGGL((mla_merge_kernel<R>), dim3((unsigned)ceil_div64(threads, 256)), dim3(256), 0, s, p);
-    return check_launch("mla_merge_kernel");
-  }
-  return 0;
+  return launch_tail<R>(p, s);
 }
 
-template <class Tag, bool PAGED>
+template <class Tag, int PAGED>
 int launch_t(int R, const MlaParams& p, bool many, hipStream_t s) {
   switch (R) {
     case 32: return launch_r<Tag, 32, PAGED>(p, many, s);
@@ -1061,9 +1120,9 @@ int mla_decode_impl(const char* what, float* out, const void* q, int64_t q_strid
     p.bs_mask = pg.block_size - 1;
     p.max_blocks = pg.max_blocks;
     p.num_blocks = pg.num_blocks;
-    return dtype == MI355_BF16 ? launch_t<BF16, true>(R, p, pl.many, s) : launch_t<F16, true>(R, p, pl.many, s);
+    return dtype == MI355_BF16 ? launch_t<BF16, kPaged>(R, p, pl.many, s) : launch_t<F16, kPaged>(R, p, pl.many, s);
   }
-  return dtype == MI355_BF16 ? launch_t<BF16, false>(R, p, pl.many, s) : launch_t<F16, false>(R, p, pl.many, s);
+  return dtype == MI355_BF16 ? launch_t<BF16, kDense>(R, p, pl.many, s) : launch_t<F16, kDense>(R, p, pl.many, s);
 }
 }  // namespace
 }  // namespace mi355

@@ -166,11 +166,19 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) mla_decode_f32
     f32x4v k[NJ];
     float v[RS], cs[RS], sn[RS];
   };
+  // Paged caches: the block id of this lane's row of the NEXT tile to be loaded (load_tile is
+  // called for consecutive tiles), fetched a call ahead and before that call's data loads, so that
+  // waiting for the id never waits for a tile in flight: loads return in order, and a table read
+  // in the address path of a tile would drain the tiles prefetched before it.
+  const int last_key = max(ctx - 1, 0);
+  int blk_ahead = 0;
+  if constexpr (PAGED) blk_ahead = bt_row[min(tok0 + c, last_key) >> p.bs_shift];
   auto load_tile = [&](int t0, Tile& x) __attribute__((always_inline)) {
-    const int key = min(t0 + c, max(ctx - 1, 0));           // (t0 counts from token 0 of the sequence)
+    const int key = min(t0 + c, last_key);                  // (t0 counts from token 0 of the sequence)
     int64_t ckv_at = (int64_t)key * p.ckv_stride_tok, kr_at = (int64_t)key * p.krope_stride_tok;
     if constexpr (PAGED) {
-      const int blk = min(max(bt_row[key >> p.bs_shift], 0), p.num_blocks - 1), r = key & p.bs_mask;
+      const int blk = min(max(blk_ahead, 0), p.num_blocks - 1), r = key & p.bs_mask;
+      blk_ahead = bt_row[min(t0 + 16 + c, last_key) >> p.bs_shift];
       ckv_at = (int64_t)blk * p.ckv_stride_blk + (int64_t)r * p.ckv_stride_tok;
       kr_at = (int64_t)blk * p.krope_stride_blk + (int64_t)r * p.krope_stride_tok;
     }
