@@ -313,12 +313,26 @@ def main():
         torch.cuda.synchronize()
 
     trace('inputs built')
-    run_steps(0, args.warmup)
+    # An idle card sits at its lowest clocks and needs tens of milliseconds of load to leave them
+    # (a timing loop that starts cold reads up to 20 % slow for its first ~15 ms).  The step itself
+    # runs for a quarter of a second first, outside the W warm-up steps and the timed region, so
+    # that a short run (a few warm-up steps, 20 timed ones) measures the same card a long one does.
+    # (A step count, not a deadline: every rank must start the same number of collectives.  About
+    # 0.25 s of steps at 6 TB/s.)
+    step_bytes = algorithmic_bytes(B, S, H, H, D, BS, 2, append=args.fused_step)
+    clock_warm_steps = int(os.environ.get('BENCH_CLOCK_WARM_STEPS', min(10000, max(500, int(0.25 * 6e12 / step_bytes)))))
+    first = 0
+    while first < clock_warm_steps:
+        n = min(200, clock_warm_steps - first)
+        run_steps(first, n)
+        first += n
+    run_steps(first, args.warmup)
+    first += args.warmup
     trace('warmup issued')
     barrier()
     trace('timed region')
     t0 = time.perf_counter()
-    run_steps(args.warmup, args.steps)
+    run_steps(first, args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -326,7 +340,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # every rank holds the whole batch's ids of the last step, its own slice among them
-    last = args.warmup + args.steps - 1
+    last = first + args.steps - 1
     got = gather.result(last)
     if args.steps > 0:
         assert got.numel() == B * world
@@ -342,7 +356,7 @@ def main():
     if rank == 0:
         torch.cuda._sleep(8_000_000)
         for j in range(ROOFLINE_LAUNCHES):
-            step(args.steps + j, bracket=j)
+            step(first + args.steps + j, bracket=j)
         torch.cuda.synchronize()
         bracket_ms = sorted(ev_a[j].elapsed_time(ev_b[j]) for j in range(ROOFLINE_LAUNCHES))
         # A pair of events around ONE launch also spans the two event packets themselves (about 2.3 us
@@ -376,7 +390,7 @@ def main():
                       f"decode tokens/sec ({args.config}" + (f", {args.strong} sequences in total" if args.strong else "") + ")",
             "value": round(B * world * args.steps / elapsed, 1),
             "unit": "tokens/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "clock_warmup_steps": clock_warm_steps,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "host_issue_ms_per_step": round(1e3 * host_issue[0] / max(args.steps, 1), 4),
             "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,

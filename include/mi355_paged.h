@@ -420,6 +420,19 @@ int mi355_paged_prefill(void* out, const void* q, int64_t q_stride_tok,
                         float scale, int32_t dtype, void* stream);
 
 /*
+ * The longest max_context mi355_paged_prefill serves for a dtype, head_dim, block size and longest
+ * segment (max_q_len), so that no caller has to learn a limit from MI355_EUNSUPPORTED: INT32_MAX
+ * where a flash-attention kernel takes the launch (16-bit head_dim 64 / 128 and fp32 head_dim
+ * 32 / 64 / 128 from MI355_PAGED_PREFILL_MIN_Q = 48 query tokens on: they read the block table from
+ * memory), otherwise the context whose block table one workgroup can stage in LDS (8190 blocks,
+ * rounded down to the kernels' token quantum), and 0 for a dtype / head_dim no kernel serves.
+ * Longer contexts go row by row through mi355_paged_decode, which splits them.  Host arithmetic
+ * only (no device call); no counterpart in the reference, whose chunked prefill never reads the
+ * cache (05_mini_vllm/mini_vllm.py:437-458).
+ */
+int32_t mi355_paged_prefill_max_context(int32_t dtype, int32_t D, int32_t block_size, int32_t max_q_len);
+
+/*
  * Data-parallel exchange of the sampled token ids, one process per GPU, over RCCL (xGMI inside a
  * node).  No counterpart in the reference, which is single-process and single-device (its only
  * collective is a commented-out all-reduce, 03_moe/mini_moe.py:356-357): sequences are sharded

@@ -280,13 +280,16 @@ def test_plan_later_chunks_become_append_segments_when_the_kernel_covers_the_mod
 
 
 def test_paged_prefill_serves_rule():
+    """The rule is the library's own (mi355_paged_prefill_max_context: host arithmetic, no device)."""
     import torch
     from mi355_paged import ops
-    limit = ops.PAGED_PREFILL_STAGED_BLOCKS * 16
-    assert ops.paged_prefill_serves(torch.float32, 32, 16, 8, limit)
-    assert not ops.paged_prefill_serves(torch.float32, 32, 16, 8, limit + 1)        # VALU kernel stages the table
+    limit = (8190 * 16 // 1024) * 1024     # blocks one workgroup stages, in tokens, down to the kernels' token quantum
+    assert ops.paged_prefill_serves(torch.float32, 16, 16, 8, limit)
+    assert not ops.paged_prefill_serves(torch.float32, 16, 16, 8, limit + 1)        # VALU kernel stages the table
     assert not ops.paged_prefill_serves(torch.bfloat16, 64, 16, 47, limit + 1)      # short chunk: append kernel, staged
     assert ops.paged_prefill_serves(torch.bfloat16, 64, 16, 48, 10 * limit)         # flash kernel reads the table itself
+    assert ops.paged_prefill_serves(torch.float32, 64, 16, 48, 10 * limit)          # ... and so does the fp32 one
+    assert not ops.paged_prefill_serves(torch.float32, 256, 16, 48, limit + 1)      # (no fp32 flash kernel at head_dim 256)
     assert not ops.paged_prefill_serves(torch.bfloat16, 48, 16, 48, 100)            # head_dim without a kernel
 
 

@@ -324,6 +324,33 @@ def test_paged_prefill_rejects_unsupported_shapes(ops, device):
         ops.paged_prefill(q, cache, cache, i32([[0, 1]]), i32([0]), i32([4]), i32([0]), 4, 4)
 
 
+@pytest.mark.parametrize('case', [(torch.float32, 16, 8), (torch.bfloat16, 64, 8)])
+def test_paged_prefill_serves_the_context_its_query_function_names(ops, device, case):
+    """mi355_paged_prefill_max_context is the longest context a launch of short segments takes: a
+    segment that ends exactly there is served (and equals paged_decode row by row, which splits the
+    context instead of staging its table); a flash-sized segment has no bound."""
+    dtype, D, nq = case
+    BS = 16
+    lib = ops._lib.load()
+    code = {torch.float32: 0, torch.bfloat16: 1}[dtype]
+    limit = lib.mi355_paged_prefill_max_context(code, D, BS, nq)
+    assert 100000 < limit <= 8190 * BS and lib.mi355_paged_prefill_max_context(code, D, BS, 64 if D == 64 else 8) in (limit, 2 ** 31 - 1)
+    assert lib.mi355_paged_prefill_max_context(code, 48, BS, nq) == 0
+    rng = np.random.default_rng(D)
+    per = limit // BS
+    g = torch.Generator(device=device).manual_seed(D)
+    cache = (torch.randn((2, per + 2, 1, BS, D), generator=g, device=device) * 0.5).to(dtype)
+    bt = torch.from_numpy(rng.permutation(per + 2)[:per].astype(np.int32)).view(1, per).to(device)
+    q = (torch.randn((nq, 1, D), generator=g, device=device)).to(dtype)
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=device)
+    got = ops.paged_prefill(q, cache[0], cache[1], bt, i32([0]), i32([nq]), i32([limit - nq]), nq, limit)
+    rows = ops.paged_decode(q, cache[0], cache[1], bt.expand(nq, per).contiguous(),
+                            i32(list(range(limit - nq + 1, limit + 1))), limit)
+    torch.cuda.synchronize()
+    tol = dict(atol=2e-6, rtol=1e-5) if dtype == torch.float32 else dict(atol=4e-3, rtol=2e-2)
+    np.testing.assert_allclose(got.float().cpu().numpy(), rows.float().cpu().numpy(), **tol)
+
+
 @pytest.mark.parametrize('shape', [
     # dtype, Hq, Hkv, D, BS, [(pos0, n_query_tokens), ...]
     (torch.float32, 4, 4, 32, 16, [(0, 40), (130, 17), (5, 1), (64, 64)]),    # the reference engine's default geometry

@@ -7,6 +7,7 @@ import sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'vllm-from-scratch_amd'))
 import torch
 from mi355_paged import ops
+from _clock import warm_card
 
 B, V = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (256, 32000)
 dev = torch.device('cuda', 0)
@@ -15,6 +16,7 @@ out = torch.empty((B,), dtype=torch.int32, device=dev)
 n = 120
 for threads in (0,):
     for rot in (len(sets), 1):
+        warm_card()
         for i in range(10):
             ops.sample_argmax(sets[i % rot], out=out)
         torch.cuda.synchronize()

@@ -6,6 +6,7 @@ import sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'vllm-from-scratch_amd'))
 import torch
 from mi355_paged import ops
+from _clock import warm_card
 
 dev = torch.device('cuda', 0)
 CASES = [  # dtype, B, S, H, D, BS
@@ -29,6 +30,7 @@ for dtype, B, S, H, D, BS in CASES:
     es = q.element_size()
     nbytes = B * S * H * D * 2 * es + 2 * B * H * D * es + 4 * B * per
     n = 30
+    warm_card()
     for i in range(5):
         ops.paged_decode(q, *pools[i % 2], ctx, S, out=out)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -5,6 +5,7 @@ import sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'vllm-from-scratch_amd'))
 import torch
 from mi355_paged import ops
+from _clock import warm_card
 
 dev = torch.device('cuda', 0)
 SHAPES = [  # B, S, Hq, Hkv, D, BS
@@ -27,6 +28,7 @@ for B, S, Hq, Hkv, D, BS in SHAPES:
     nbytes = B * S * Hkv * D * 2 * 2 + 2 * B * Hq * D * 2 + 4 * B * per
     n = 30
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    warm_card()
     for i in range(n + 5):
         kc, vc, bt = pools[i % 2]
         if i >= 5:

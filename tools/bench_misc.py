@@ -7,11 +7,13 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 import torch
 from bench import CONFIGS, build_inputs
 from mi355_paged import ops
+from _clock import warm_card
 
 dev = torch.device('cuda', 0)
 
 
 def timeit(fn, n=50, warm=5):
+    warm_card(0.2)
     for _ in range(warm):
         fn()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -6,6 +6,7 @@ import sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'vllm-from-scratch_amd'))
 import torch
 from mi355_paged import ops
+from _clock import warm_card
 
 nseg, chunk, pos0, Hq, Hkv, D = ([int(x) for x in sys.argv[1:7]] + [8, 1024, 3072, 32, 8, 128])[:6]
 dtype = getattr(torch, sys.argv[7]) if len(sys.argv) > 7 else torch.bfloat16
@@ -26,6 +27,7 @@ p0 = torch.full((nseg,), pos0, dtype=torch.int32, device=dev)
 out = torch.empty_like(q)
 # every query token i of a chunk sees pos0 + i + 1 keys
 flops = 4.0 * Hq * D * nseg * sum(pos0 + i + 1 for i in range(chunk))
+warm_card()
 for _ in range(3):
     ops.paged_prefill(q, kc, vc, bt, start, lens, p0, chunk, ctx, layout='NSHD', out=out)
 n = 20

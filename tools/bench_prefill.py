@@ -6,6 +6,7 @@ import sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'vllm-from-scratch_amd'))
 import torch
 from mi355_paged import ops
+from _clock import warm_card
 
 args = [int(x) for x in sys.argv[1:]] or [16, 2048, 8, 8, 64]
 nseq, L, Hq, Hkv, D = args
@@ -21,6 +22,7 @@ flops = 4.0 * nseq * Hq * D * (L * (L + 1) / 2)          # QK^T + PV over the ca
 for name, env in (('mfma', None), ('valu', '1'))[:1 if os.environ.get('BENCH_MFMA_ONLY') else 2]:
     ops._lib.load().mi355_debug_set_knob(b'MI355_PREFILL_VALU', int(env or 0))
     n = 20 if name == 'mfma' else 5
+    warm_card()
     for _ in range(3):
         ops.prefill_causal(q, k, v, cu, L)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -9,6 +9,7 @@ import time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'vllm-from-scratch_amd'))
 import torch
 from mi355_paged import ops
+from _clock import warm_card
 
 args = sys.argv[1:]
 nseq, L, Hq, Hkv, D = [int(x) for x in args[:5]] if len(args) >= 5 else [16, 2048, 8, 8, 64]
@@ -29,6 +30,7 @@ for name, mfma, tiled, env in (('matrix cores (fp32 MFMA)', 1, '1', '1'), ('one 
     ops._lib.load().mi355_debug_set_knob(b'MI355_PREFILL_F32_MFMA', mfma)
     ops._lib.load().mi355_debug_set_knob(b'MI355_PREFILL_F32_TILED', int(tiled))
     ops._lib.load().mi355_debug_set_knob(b'MI355_PREFILL_ROW_GROUPS', int(env))
+    warm_card()
     for _ in range(2):
         outs[name] = ops.prefill_causal(q, k, v, cu, L)
     n = 5

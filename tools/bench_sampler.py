@@ -6,6 +6,7 @@ import sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'vllm-from-scratch_amd'))
 import torch
 from mi355_paged import ops
+from _clock import warm_card
 
 B, V = ([int(x) for x in sys.argv[1:3]] + [256, 32000])[:2]
 STD = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
@@ -26,6 +27,7 @@ only = os.environ.get('SAMPLER_MODES')
 for name, fn in modes.items():
     if only and name not in only.split(';'):
         continue
+    warm_card(0.2)
     for i in range(5):
         fn(logits[i % 4])
     n = 40

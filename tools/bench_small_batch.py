@@ -6,6 +6,7 @@ import sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'vllm-from-scratch_amd'))
 import torch
 from mi355_paged import ops
+from _clock import warm_card
 
 dev = torch.device('cuda', 0)
 BS = 16
@@ -26,6 +27,7 @@ for Hq, Hkv, D in ((8, 8, 64), (32, 8, 128)):
         ctx = torch.full((B,), S, dtype=torch.int32, device=dev)
         out = torch.empty_like(q)
         n = 40
+        warm_card(0.3)
         for i in range(6):
             ops.paged_decode(q, *pools[i % sets], ctx, S, out=out)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

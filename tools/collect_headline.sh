@@ -17,12 +17,15 @@ step() { echo "== $*" >&2; }
 
 for cfg in metric c2; do
   step "counters $cfg"
+  # (counter passes serialise the launches: a short clock warm-up; bytes per launch do not depend on clocks)
+  export BENCH_CLOCK_WARM_STEPS=50
   timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_$cfg" -o fetch -- \
     python3 bench.py --config $cfg --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2> "$OUT/pmc_fetch_$cfg.log"
   timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_$cfg" -o write -- \
     python3 bench.py --config $cfg --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2> "$OUT/pmc_write_$cfg.log"
   python3 tools/pmc_traffic.py "$(find "$OUT/pmc_fetch_$cfg" -name '*counter_collection.csv' | head -1)" \
     "$(find "$OUT/pmc_write_$cfg" -name '*counter_collection.csv' | head -1)" "$OUT/pmc_traffic_$cfg.json" "$SHA" > /dev/null
+  unset BENCH_CLOCK_WARM_STEPS
   step "kernel trace $cfg"
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_$cfg" -o $cfg -- \
     python3 bench.py --config $cfg --steps 100 --no-cpu-baseline > "$OUT/bench_line_${cfg}_under_rocprof.json" 2> "$OUT/trace_$cfg.log"

@@ -1224,6 +1224,19 @@ extern "C" int mi355_paged_decode_static(void* out, const void* q, int64_t q_str
                            stream);
 }
 
+extern "C" int32_t mi355_paged_prefill_max_context(int32_t dtype, int32_t D, int32_t block_size, int32_t max_q_len) {
+  if (dtype != MI355_F32 && dtype != MI355_BF16 && dtype != MI355_F16) return 0;
+  if (D != 16 && D != 32 && D != 64 && D != 128 && D != 256) return 0;
+  if (block_size <= 0 || max_q_len < 0) return 0;
+  const bool many = max_q_len >= knob(kKnobPagedPrefillMinQ);
+  if (many && (prefill_mfma_supported(dtype, D) || (prefill_mfma_f32_supported(dtype, D) && knob(kKnobPrefillF32Mfma))))
+    return INT32_MAX;
+  // the staging kernels round the context up to their token quantum (a power of two <= 1024) before
+  // they size the table slice: kMaxBtEntries - 2 blocks, rounded down to a multiple of every quantum
+  const int64_t staged = ((int64_t)(kMaxBtEntries - 2) * block_size / 1024) * 1024;
+  return (int32_t)(staged < INT32_MAX ? staged : INT32_MAX);
+}
+
 extern "C" int mi355_paged_prefill(void* out, const void* q, int64_t q_stride_tok, const void* k_cache,
                                    const void* v_cache, const int32_t* block_tables, const int32_t* seg_q_start,
                                    const int32_t* seg_len, const int32_t* seg_pos0, int32_t nseg,

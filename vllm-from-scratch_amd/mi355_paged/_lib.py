@@ -63,6 +63,7 @@ SIGNATURES = {
         c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
         c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
         c_int64, c_int64, c_int64, c_float, c_int32, c_void_p]),
+    'mi355_paged_prefill_max_context': (c_int32, [c_int32, c_int32, c_int32, c_int32]),
     'mi355_decode_step_inputs': (c_int, [
         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
         c_int32, c_int32, c_int32, c_void_p]),

@@ -701,21 +701,16 @@ def paged_prefill_supported(dtype: torch.dtype, head_dim: int) -> bool:
             and head_dim in (16, 32, 64, 128, 256))
 
 
-PAGED_PREFILL_STAGED_BLOCKS = 8190     # block-table entries one workgroup of the LDS-staging kernels can hold
-PAGED_PREFILL_FLASH_MIN_Q = 48         # from this chunk length on, 16-bit head_dim 64 / 128 chunks take the flash kernel
-
-
 def paged_prefill_serves(dtype: torch.dtype, head_dim: int, block_size: int, n_q: int, context: int) -> bool:
     """Can a segment of n_q new tokens whose last one sits at position context - 1 be part of a
-    paged_prefill launch?  The flash-attention kernel (16-bit, head_dim 64 / 128, taken when the
-    longest segment of the launch has >= 48 tokens) reads the block table from memory and has no
-    context limit; the other two kernels stage a sequence's whole table in LDS, which bounds the
-    context at PAGED_PREFILL_STAGED_BLOCKS blocks.  Segments beyond that go row by row through
-    paged_decode, which splits long contexts."""
+    paged_prefill launch?  The library answers (mi355_paged_prefill_max_context): its flash-attention
+    kernels (chunks of >= 48 tokens; 16-bit head_dim 64 / 128, fp32 head_dim 32 / 64 / 128) read the
+    block table from memory and have no context limit; the other kernels stage a sequence's whole
+    table in LDS, which bounds the context at about 8190 blocks.  Segments beyond that go row by row
+    through paged_decode, which splits long contexts."""
     if not paged_prefill_supported(dtype, head_dim):
         return False
-    flash = dtype in (torch.bfloat16, torch.float16) and head_dim in (64, 128) and n_q >= PAGED_PREFILL_FLASH_MIN_Q
-    return flash or context <= PAGED_PREFILL_STAGED_BLOCKS * block_size
+    return context <= _lib.load().mi355_paged_prefill_max_context(_DTYPE_CODE[dtype], head_dim, block_size, n_q)
 
 
 def paged_prefill(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, block_tables: torch.Tensor,
