@@ -410,7 +410,7 @@ def test_engine_step_scheduled_ahead_that_cannot_be_issued_ahead(device, monkeyp
     by then its decode items carry real ids and requests that ended meanwhile are dropped."""
     import mini_vllm as mv
     from mi355_paged import ops as _ops
-    monkeypatch.setattr(_ops, 'PAGED_PREFILL_STAGED_BLOCKS', 32)
+    monkeypatch.setattr(_ops, 'paged_prefill_serves', lambda dtype, head_dim, bs, n_q, context: context <= 32 * bs)
     rng = np.random.default_rng(5)
     lens = [300, 20, 12, 330, 9, 40, 280, 15, 22, 310, 7, 18]
     prompts = [[int(t) for t in rng.integers(1, 12, size=n)] for n in lens]
