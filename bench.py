@@ -14,9 +14,16 @@ One step = one decode step of one attention layer for the whole batch:
   (3) greedy sampling from fp32 logits [256, 32000]      (mi355_sample_argmax)
   (4) with N > 1: all-gather of the sampled ids across ranks (RCCL), one collective per step,
       asynchronous: ranks do not need each other's ids to go on decoding, so a collective
-      overlaps the steps after it.  --gather-every k (not the default) sends the ids of k
-      consecutive steps in one collective and says so in `config.workload`.  Every id is
-      exchanged, and every collective has completed, before the timed region closes.
+      overlaps the steps after it.  By default the library's own communicator runs it on a
+      low-priority side stream behind a one-wave watcher kernel that returns once the step's ids
+      are written (mi355_dp_exchange_*): the stream of steps (1)-(3) carries nothing for the
+      exchange.  BENCH_EXCHANGE=native (event record + stream wait per step) and =torch
+      (torch.distributed) select the earlier forms; `config.exchange` says which one ran.
+      --gather-every k (not the default) sends the ids of k consecutive steps in one collective
+      and says so in `config.workload`.  Every id is exchanged, and every collective has
+      completed, before the timed region closes.
+Before the --warmup steps the step runs untimed for about a quarter of a second
+(`clock_warmup_steps`): an idle card sits at its lowest clocks for its first tens of milliseconds.
 `value` = sequences (= tokens) decoded per second over all ranks; the timed region holds exactly
 --steps steps and no instrumentation.  `roofline` prices step (2), the dominant kernel, against
 HBM bandwidth: algorithmic bytes / the average launch duration by HIP events on the launch stream,

@@ -457,7 +457,10 @@ int mi355_dp_destroy(void* comm);
  * the ids carries no event record, no wait and no extra launch, its sampler is the plain one, and
  * ranks do not wait for each other on it.  (Measured on this chip: an event record + stream wait
  * per step costs the producing stream 3.9 us, 1.5 us without the system fence; a wait for a value
- * in signal memory, hipStreamWaitValue64, runs as a polling kernel of the runtime's own.)
+ * in signal memory, hipStreamWaitValue64, runs as a polling kernel of the runtime's own.)  The side
+ * stream is created with the lowest priority the device offers: a second queue of the default
+ * priority that is busy or waiting slows the workgroup dispatch of the producing stream (a
+ * 2048-workgroup decode launch by 3 us); behind a low-priority queue it costs 0.3-0.5 us per step.
  * Token ids are non-negative; "not written" is -1.
  *   mi355_dp_exchange_create: with the communicator's device current.
  *   mi355_dp_exchange_arm: marks send[0 .. count) as not written (synchronous); once per send

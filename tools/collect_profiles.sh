@@ -1,14 +1,17 @@
 #!/bin/bash
 # Collect the measurements kept under profiles/: run on the GPU box from the repo root,
-#   tools/collect_profiles.sh <tag>      (writes gpurun_out/<tag>/...)
-# Kernel-trace passes and counter (--pmc) passes are separate rocprofv3 runs.
+#   tools/collect_profiles.sh <tag> [traces|secondary|all]      (writes gpurun_out/<tag>/...)
+# Kernel-trace passes and counter (--pmc) passes are separate rocprofv3 runs.  The two halves fit a
+# 20-minute GPU call each: "traces" = headline set, kernel traces, counters; "secondary" = the rest.
 set -e
 TAG=${1:-r1f}
+PART=${2:-all}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 step() { echo "== $*" >&2; }
 
+if [ "$PART" != secondary ]; then
 step headline: bench lines, kernel traces and HBM-traffic counters of the metric config and config 2
 tools/collect_headline.sh "$TAG" > "$OUT/headline.txt" 2> "$OUT/headline.err"
 
@@ -27,6 +30,18 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/
   python3 tools/bench_engine_mixed.py 512 128 2048 > "$OUT/engine_under_rocprof.txt" 2> "$OUT/trace_engine.log"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_prefill_f32" -o prefill_f32 -- \
   python3 tools/bench_prefill_fp32.py 16 2048 8 8 64 > "$OUT/prefill_f32_under_rocprof.txt" 2> "$OUT/trace_prefill_f32.log"
+step kernels of one captured decode step of the engine
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace_engine_decode" -o engdec -- \
+  python3 tools/bench_engine.py 256 512 32 > "$OUT/engine_decode_under_rocprof.txt" 2> "$OUT/trace_engine_decode.log"
+python3 tools/trace_decode_step.py "$(find "$OUT/trace_engine_decode" -name '*kernel_trace.csv' | head -1)" > "$OUT/engine_decode_step_kernels.txt"
+step kernel trace of the one-rank rehearsal of the N > 1 step, exchange started by the GPU
+MASTER_ADDR=127.0.0.1 MASTER_PORT=29519 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 BENCH_FORCE_DIST=1 \
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_exchange" -o exchange -- \
+  python3 bench.py --no-cpu-baseline --steps 100 > "$OUT/bench_line_exchange_under_rocprof.json" 2> "$OUT/trace_exchange.log"
+if [ -f tools/_ab/lib_samp_t.so ]; then
+  step sampler phases from the stamped side build
+  MI355_PAGED_LIB=tools/_ab/lib_samp_t.so timeout -k 10 200 python3 tools/probe_sampler_phases.py > "$OUT/sampler_phases.txt" 2> "$OUT/sampler_phases.err"
+fi
 
 step counters: MFMA activity of the prefill kernels, MLA
 BENCH_MFMA_ONLY=1 tools/pmc_sq.sh "$OUT/pmc_prefill_d128" prefill_mfma tools/bench_prefill.py 4 8192 32 8 128 > "$OUT/pmc_prefill_d128.txt"
@@ -36,6 +51,8 @@ MLA_TARGETS=0 tools/pmc_sq.sh "$OUT/pmc_mla_mh" mla_decode_kernel_mh tools/bench
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_mla_fetch" -o fetch -- \
   python3 tools/bench_mla.py 256 16 4096 > /dev/null 2> "$OUT/pmc_mla_fetch.log"
 
+fi
+if [ "$PART" = traces ]; then exit 0; fi
 step secondary benchmarks
 {
   timeout -k 10 200 python3 tools/bench_misc.py
@@ -48,6 +65,12 @@ step secondary benchmarks
   timeout -k 10 200 python3 tools/bench_argmax.py
   timeout -k 10 200 python3 tools/bench_argmax.py 256 1000
   for a in "64 16 4096" "256 16 4096" "128 16 8192" "64 32 4096" "32 64 4096" "128 128 4096"; do MLA_TARGETS=0,0 timeout -k 10 120 python3 tools/bench_mla.py $a | tail -1; done
+  echo "the same rows in randomly placed blocks of 16 tokens, a pool each for c_kv and k_rope (mi355_mla_decode_paged); one pool of R + P wide rows; fp32"
+  for a in "64 16 4096" "256 16 4096" "128 128 4096"; do MLA_PAGED=16 MLA_PAGED_SPLIT=1 MLA_TARGETS=0 timeout -k 10 120 python3 tools/bench_mla.py $a | tail -1; done
+  MLA_PAGED=16 MLA_TARGETS=0 timeout -k 10 120 python3 tools/bench_mla.py 256 16 4096 | tail -1
+  MLA_PAGED=16 MLA_PAGED_SPLIT=1 MLA_TARGETS=0 timeout -k 10 120 python3 tools/bench_mla.py 256 16 4096 float32 | tail -1
+  echo "a timing loop on a cold card (no clock warm-up), two loops in a row"
+  MLA_WARM_SECONDS=0 MLA_TARGETS=0,0 timeout -k 10 120 python3 tools/bench_mla.py 256 16 4096 | tail -2
   MI355_MLA_MANY_HEADS=0 MLA_TARGETS=0 timeout -k 10 120 python3 tools/bench_mla.py 128 128 4096 | tail -1 | sed 's/^/16 heads per workgroup: /'
   timeout -k 10 200 python3 tools/bench_small_batch.py
   timeout -k 10 200 python3 tools/ab_fused_merge.py
@@ -63,17 +86,19 @@ step secondary benchmarks
   for a in "8 1024 3072 32 8 128" "8 1024 3072 8 8 64" "32 256 256 8 8 64" "64 64 1024 8 8 64"; do timeout -k 10 120 python3 tools/bench_paged_prefill.py $a; done
   timeout -k 10 200 python3 tools/bench_dtypes.py
   timeout -k 10 200 python3 tools/bench_engine.py 256 512 32
+  echo "... with the decode branch as RoPE + cache write, then attention (two launches) instead of one"
+  ENGINE_FUSED_DECODE=0 timeout -k 10 200 python3 tools/bench_engine.py 256 512 32
   timeout -k 10 200 python3 tools/bench_engine.py 128 256 64
   timeout -k 10 200 python3 tools/bench_engine.py 8 4096 8 1024
   timeout -k 10 200 python3 tools/bench_engine_mixed.py 512 128 2048
   timeout -k 10 200 python3 tools/time_mixed_steps.py 512 128 2048
   timeout -k 10 200 python3 tools/bench_reference_engine_config.py
   export MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0
-  echo "one-rank RCCL communicator (BENCH_FORCE_DIST=1): gather every step (default), every 4 steps, native every step, none"
-  BENCH_FORCE_DIST=1 timeout -k 10 200 python3 bench.py --no-cpu-baseline | cut -c1-200
-  BENCH_FORCE_DIST=1 timeout -k 10 200 python3 bench.py --no-cpu-baseline --gather-every 4 | cut -c1-200
-  BENCH_FORCE_DIST=1 BENCH_NATIVE_RCCL=1 timeout -k 10 200 python3 bench.py --no-cpu-baseline | cut -c1-200
-  timeout -k 10 200 python3 bench.py --no-cpu-baseline | cut -c1-200
+  echo "one-rank RCCL communicator (BENCH_FORCE_DIST=1), one collective per step: exchange started by the GPU (default), library communicator behind event + wait, torch.distributed; then no collective; twice"
+  tools/bench_exchange.sh metric || echo "exchange rehearsal failed"
+  tools/bench_exchange.sh metric || echo "exchange rehearsal failed"
+  echo "... one collective per 4 steps (library communicator)"
+  BENCH_FORCE_DIST=1 timeout -k 10 200 python3 bench.py --no-cpu-baseline --gather-every 4 | cut -c1-260
   echo "cache write + attention in one launch (--fused-step) against the two launches of the default step: metric config, config 2"
   timeout -k 10 200 python3 bench.py --no-cpu-baseline --fused-step
   timeout -k 10 200 python3 bench.py --no-cpu-baseline

@@ -25,6 +25,12 @@ for rel, name in [('secondary.txt', 'secondary_benchmarks.txt'),
     put(rel, name)
 for name in ('gqa', 'mla', 'prefill', 'engine', 'prefill_f32', 'c2tune'):
     put(f'trace_{name}/{name}_kernel_stats.csv', f'{name}_kernel_stats.csv')
+for rel, name in [('engine_decode_step_kernels.txt', 'engine_decode_step_kernels.txt'),
+                  ('sampler_phases.txt', 'sampler_phases.txt'),
+                  ('trace_exchange/exchange_kernel_stats.csv', 'exchange_kernel_stats.csv'),
+                  ('bench_line_exchange_under_rocprof.json', 'bench_line_exchange_under_rocprof.json')]:
+    if os.path.exists(os.path.join(src, rel)):
+        put(rel, name)
 put('trace_paged_prefill/pp_kernel_stats.csv', 'paged_prefill_kernel_stats.csv')
 
 
