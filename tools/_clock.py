@@ -5,6 +5,7 @@ timing loop that starts on a cold card reads up to 20 % slow for its first ~15 m
 at 256 rows x 4096 tokens: 217 us, then 187, then 182 for three 65-launch loops in a row in one
 process).  warm_card() keeps the card busy for half a second; the scripts call it right before
 their own few warm-up calls of the kernel they time."""
+import os
 import time
 
 import torch
@@ -13,6 +14,7 @@ _buf = {}
 
 
 def warm_card(seconds: float = 0.5) -> None:
+    seconds = float(os.environ.get('MI355_WARM_SECONDS', seconds))     # (counter passes shorten it)
     dev = torch.device('cuda', torch.cuda.current_device())
     if dev not in _buf:
         _buf[dev] = (torch.randn((4096, 4096), device=dev, dtype=torch.bfloat16),

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Collect the measurements kept under profiles/: run on the GPU box from the repo root,
-#   tools/collect_profiles.sh <tag> [traces|secondary|all]      (writes gpurun_out/<tag>/...)
+#   tools/collect_profiles.sh <tag> [traces|secondary|secondary1|secondary2|all]      (writes gpurun_out/<tag>/...)
 # Kernel-trace passes and counter (--pmc) passes are separate rocprofv3 runs.  The two halves fit a
-# 20-minute GPU call each: "traces" = headline set, kernel traces, counters; "secondary" = the rest.
+# 20-minute GPU call each: "traces" = headline set, kernel traces, counters; "secondary" = the rest (secondary1 + secondary2: secondary_a.txt, secondary_b.txt).
 set -e
 TAG=${1:-r1f}
 PART=${2:-all}
@@ -11,7 +11,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 step() { echo "== $*" >&2; }
 
-if [ "$PART" != secondary ]; then
+if [ "$PART" = traces ] || [ "$PART" = all ]; then
 step headline: bench lines, kernel traces and HBM-traffic counters of the metric config and config 2
 tools/collect_headline.sh "$TAG" > "$OUT/headline.txt" 2> "$OUT/headline.err"
 
@@ -34,7 +34,7 @@ step kernels of one captured decode step of the engine
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace_engine_decode" -o engdec -- \
   python3 tools/bench_engine.py 256 512 32 > "$OUT/engine_decode_under_rocprof.txt" 2> "$OUT/trace_engine_decode.log"
 python3 tools/trace_decode_step.py "$(find "$OUT/trace_engine_decode" -name '*kernel_trace.csv' | head -1)" > "$OUT/engine_decode_step_kernels.txt"
-step kernel trace of the one-rank rehearsal of the N > 1 step, exchange started by the GPU
+step "kernel trace of the one-rank rehearsal of the multi-rank step, exchange started by the GPU"
 MASTER_ADDR=127.0.0.1 MASTER_PORT=29519 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 BENCH_FORCE_DIST=1 \
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_exchange" -o exchange -- \
   python3 bench.py --no-cpu-baseline --steps 100 > "$OUT/bench_line_exchange_under_rocprof.json" 2> "$OUT/trace_exchange.log"
@@ -44,6 +44,7 @@ if [ -f tools/_ab/lib_samp_t.so ]; then
 fi
 
 step counters: MFMA activity of the prefill kernels, MLA
+export MI355_WARM_SECONDS=0.05 MLA_WARM_SECONDS=0.05   # (counter passes serialise launches; counts do not depend on clocks)
 BENCH_MFMA_ONLY=1 tools/pmc_sq.sh "$OUT/pmc_prefill_d128" prefill_mfma tools/bench_prefill.py 4 8192 32 8 128 > "$OUT/pmc_prefill_d128.txt"
 BENCH_MFMA_ONLY=1 tools/pmc_sq.sh "$OUT/pmc_prefill_d64" prefill_mfma tools/bench_prefill.py 2 16384 8 8 64 > "$OUT/pmc_prefill_d64.txt"
 tools/pmc_sq.sh "$OUT/pmc_prefill_f32" prefill_mfma_f32 tools/bench_prefill_fp32.py 16 2048 8 8 64 > "$OUT/pmc_prefill_f32.txt"
@@ -51,9 +52,13 @@ MLA_TARGETS=0 tools/pmc_sq.sh "$OUT/pmc_mla_mh" mla_decode_kernel_mh tools/bench
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_mla_fetch" -o fetch -- \
   python3 tools/bench_mla.py 256 16 4096 > /dev/null 2> "$OUT/pmc_mla_fetch.log"
 
+# what comes back from the box is capped at 64 MiB: the per-launch traces have been digested above
+find "$OUT" -name '*kernel_trace.csv' -size +1M -delete
 fi
 if [ "$PART" = traces ]; then exit 0; fi
+unset MI355_WARM_SECONDS MLA_WARM_SECONDS
 step secondary benchmarks
+if [ "$PART" != secondary2 ]; then
 {
   timeout -k 10 200 python3 tools/bench_misc.py
   timeout -k 10 200 python3 tools/bench_sampler.py
@@ -84,6 +89,10 @@ step secondary benchmarks
   timeout -k 10 120 python3 tools/bench_paged_prefill.py 8 1024 3072 8 8 64 float32
   MLA_TARGETS=0 timeout -k 10 120 python3 tools/bench_mla.py 256 16 4096 float32 | tail -1
   for a in "8 1024 3072 32 8 128" "8 1024 3072 8 8 64" "32 256 256 8 8 64" "64 64 1024 8 8 64"; do timeout -k 10 120 python3 tools/bench_paged_prefill.py $a; done
+} > "$OUT/secondary_a.txt" 2> "$OUT/secondary_a.err"
+fi
+if [ "$PART" = secondary1 ]; then exit 0; fi
+{
   timeout -k 10 200 python3 tools/bench_dtypes.py
   timeout -k 10 200 python3 tools/bench_engine.py 256 512 32
   echo "... with the decode branch as RoPE + cache write, then attention (two launches) instead of one"
@@ -106,5 +115,5 @@ step secondary benchmarks
   timeout -k 10 200 python3 bench.py --no-cpu-baseline --config c2
   echo "fixed total batch (--strong 2048) on one GPU: 2048 sequences in one launch"
   timeout -k 10 200 python3 bench.py --no-cpu-baseline --strong 2048
-} > "$OUT/secondary.txt" 2> "$OUT/secondary.err"
+} > "$OUT/secondary_b.txt" 2> "$OUT/secondary_b.err"
 find "$OUT" -name '*.csv' | head -40 >&2

@@ -20,9 +20,11 @@ def put(rel, name):
 
 
 subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'publish_headline.py'), tag])
-for rel, name in [('secondary.txt', 'secondary_benchmarks.txt'),
-                  ('pmc_mla_fetch/fetch_counter_collection.csv', 'pmc_mla_fetch_size.csv')]:
-    put(rel, name)
+with open(os.path.join(dst, f'{tag}_secondary_benchmarks.txt'), 'w') as f:      # (collected in one or two GPU calls)
+    for part in ('secondary.txt', 'secondary_a.txt', 'secondary_b.txt'):
+        if os.path.exists(os.path.join(src, part)):
+            f.write(open(os.path.join(src, part)).read())
+put('pmc_mla_fetch/fetch_counter_collection.csv', 'pmc_mla_fetch_size.csv')
 for name in ('gqa', 'mla', 'prefill', 'engine', 'prefill_f32', 'c2tune'):
     put(f'trace_{name}/{name}_kernel_stats.csv', f'{name}_kernel_stats.csv')
 for rel, name in [('engine_decode_step_kernels.txt', 'engine_decode_step_kernels.txt'),
