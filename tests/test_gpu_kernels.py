@@ -1174,6 +1174,12 @@ def test_sampling_top_k_on_register_rows_from_the_candidate_list(ops, device, vo
     peaked = np.full(vocab, -200.0, dtype=np.float32)      # five positive weights, the rest underflow
     peaked[[3, 17, 400, 401, vocab - 1]] = [5.0, 4.0, 4.0, 3.0, 1.0]
     rows.append(peaked); top_ps.append(1.0); top_ks.append(12)
+    # the k-th largest value is the list's bound itself: sixteen equal maxima, one in each wave's share of the row
+    # (a thread owns the elements of 16-byte pieces tid, tid + 1024, ...), and more of the same value just below
+    # the list's reach would tie with them -- the row must come out as the walk over the whole row gives it
+    tied = (rng.standard_normal(vocab) * 0.5 - 6.0).astype(np.float32)
+    tied[[min(256 * w, vocab - 1 - w) for w in range(16)]] = 3.0
+    rows.append(tied); top_ps.append(1.0); top_ks.append(8)
     nrow = len(rows)
     logits = torch.from_numpy(np.stack(rows)).to(device)
     temps = torch.ones(nrow, device=device)

@@ -21,7 +21,7 @@ NAMES = {0: 'start', 1: 'loaded + max', 2: 'exp + sum', 3: 'L0 bins zeroed', 4: 
          7: 'L0 list built', 8: 'L1 zeroed', 9: 'L1 tallied', 10: 'L1 scanned', 11: 'L1 cut', 12: 'L1 end', 13: 'L2 zeroed',
          14: 'L2 tallied', 15: 'L2 scanned', 16: 'L2 cut', 17: 'L2 end', 18: 'search done', 19: 'ties done', 20: 'draw start',
          21: 'draw scanned', 22: 'picker known', 23: 'walk',
-         24: 'list: bound', 25: 'list: collected', 26: 'list: ordered', 27: 'list: picked'}
+         24: 'list: counted', 25: 'list: normalised', 26: 'list: ordered', 27: 'list: picked'}
 for label, tp, tk in (('top_k=50', 1.0, 50), ('top_p=0.9', 0.9, 0), ('top_p=0.5', 0.5, 0)):
     top_p = torch.full((B,), tp, device=dev)
     top_k = torch.full((B,), tk, dtype=torch.int32, device=dev)

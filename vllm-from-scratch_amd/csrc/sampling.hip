@@ -362,7 +362,8 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
   __shared__ float s_walk_base;
   __shared__ float s_uniform;
   int slot = 0;
-  const int tid = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
+  constexpr int nt = NT;              // (every launch of this kernel has NT threads: indices are tid + constants)
+  const int tid = threadIdx.x, b = blockIdx.x;
   STAMP(0);
   const int lane = tid & 63, wave = tid >> 6;
   // The row's one random number, by one thread while the row's first loads are in the air (its ten
@@ -476,6 +477,27 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
       pr[j] = (eidx(j) < vocab) ? pr[j] : -__builtin_inff();
       mx = fmaxf(mx, pr[j]);
     }
+    // Under a top-k limit of up to 128 the cut, the tie rule, the kept mass and the draw are taken
+    // from a short list of candidates (see the list section below).  Its lower bound is known here
+    // already, in x / T: every wave takes the k'-th largest of its lanes' largest values, k' =
+    // ceil(k / waves) -- at least k' different elements are >= it, so the smallest of the waves'
+    // values has at least k elements at or above it.  (The reduction below publishes the bounds.)
+    const int list_per_wave = tk > 0 ? (tk + (nt >> 6) - 1) / (nt >> 6) : 0;
+    const bool list_try = list_per_wave >= 1 && list_per_wave <= 8;   // (the same for the whole row)
+    if (list_try) {
+      float top = mx, kth = -__builtin_inff();
+      for (int r = 0; r < list_per_wave; ++r) {
+        kth = wave_reduce(top, fmaxop);
+        const unsigned long long holders = __ballot(top == kth);
+        if (lane == __ffsll((long long)holders) - 1) top = -__builtin_inff();   // one lane gives its value up per round
+      }
+      if (lane == 0) s_top_bound[wave] = kth;
+      if (tid == 0) s_cand_n = 0;
+      if (tid < kTopCap) {
+        s_top_rank[tid] = 0;
+        s_top_key[tid] = 0ull;                             // (entries past the list: behind every candidate)
+      }
+    }
     mx = block_reduce(mx, fmaxop, xch, slot);
     STAMP(1);
     // A row without a cut whose distribution nobody asked for only needs its draw: weights
@@ -523,87 +545,76 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
       if (wave == 0) walk_pick(picker, target);
       return;
     }
+    // The candidates of the list path are picked up in the pass that exponentiates: x / T at or above
+    // the bound -- a hundred or two of 32000 -- goes to LDS as one 64-bit key, weight bits above the
+    // complemented index; most rounds of a wave find none and cost a comparison and a scalar branch.
+    // A bound whose weight underflows to 0 (fewer than k positive weights) means no list.
+    float lowest_x = __builtin_inff();                   // nothing is a candidate
+    if (list_try) {
+      float lo = s_top_bound[0];
 #pragma unroll
-    for (int j = 0; j < VPT; ++j) {
-      pr[j] = exp_nonpos(pr[j] - mx);    // absent elements: exp(-inf) = 0
-      z += pr[j];
+      for (int w = 1; w < kMaxWaves; ++w) lo = fminf(lo, s_top_bound[w < (nt >> 6) ? w : 0]);
+      if (exp_nonpos(lo - mx) > 0.f) lowest_x = lo;      // (-inf: a wave without k' values)
+    }
+    const bool list_on = lowest_x < __builtin_inff();
+    if (list_on) {                                       // (wave-uniform; rows without a list keep the bare loop)
+#pragma unroll
+      for (int j = 0; j < VPT; ++j) {
+        const float x = pr[j];
+        const float e = exp_nonpos(x - mx);              // absent elements: exp(-inf) = 0
+        pr[j] = e;
+        z += e;
+        const bool hit = x >= lowest_x;
+        const unsigned long long hits = __ballot(hit);
+        if (hits) {                                      // (wave-uniform)
+          int at = 0;
+          if (lane == 0) at = atomicAdd(&s_cand_n, __popcll(hits));
+          at = __builtin_amdgcn_readfirstlane(at) +
+               (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u));
+          // (the element's index is formed here, from a thread id the compiler cannot match with the
+          // one the load pass used: shared with that pass, all 32 indices stay live across the loop
+          // and push the kernel past its 128 registers)
+          int t = tid;
+          asm volatile("" : "+v"(t));
+          const int idx = VEC ? ((j / EPL) * nt + t) * EPL + (j % EPL) : j * nt + t;
+          if (hit && at < kTopCap)
+            s_top_key[at] = ((unsigned long long)__builtin_bit_cast(uint32_t, e) << 32) | (uint32_t)~idx;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < VPT; ++j) {
+        pr[j] = exp_nonpos(pr[j] - mx);                  // absent elements: exp(-inf) = 0
+        z += pr[j];
+      }
     }
     z = block_reduce(z, addf, xch, slot);
     const float inv_z = 1.0f / z;
     STAMP(2);
-    // Under a top-k limit of up to 128 the whole rest of the row's work -- cut, tie rule, kept
-    // mass, draw -- is done on a short list.  A lower bound of the k-th largest weight comes from
-    // the threads' largest weights (every wave takes the k'-th largest of its lanes' largest,
-    // k' = ceil(k / waves): at least k' different elements are >= it, so the smallest of the waves'
-    // values has at least k elements at or above it); the elements at or above it -- a hundred or
-    // two of 32000 -- go to LDS with their indices, only they are normalised (by the expression
-    // every other path uses, so probabilities are the same bits), each finds its place in the
-    // descending order (ties: lower index first, the stable sort of the reference,
-    // 05_mini_vllm/mini_vllm.py:620) by counting the candidates ahead of it, and the first k in
-    // that order are everything the cut and the draw need: no histogram over the row, no
-    // normalisation of the row, no pass for the kept mass.  What lies above a value is summed as
-    // the histogram bins would sum it (packed_prob: exact, order-free), so the kept set is the
-    // one the bin search finds.  A row whose candidates do not fit (long constant stretches, fewer
-    // than k positive weights) takes the general path below.
+    // The list: only the candidates are normalised (by the expression every other path uses, so
+    // probabilities are the same bits), each finds its place in the descending order (ties: lower
+    // index first, the stable sort of the reference, 05_mini_vllm/mini_vllm.py:620) by counting the
+    // candidates ahead of it, and the first k in that order are everything the cut and the draw
+    // need: no histogram over the row, no normalisation of the row, no pass for the kept mass.
+    // What lies above a value is summed as the histogram bins would sum it (packed_prob: exact,
+    // order-free), so the kept set is the one the bin search finds.  A larger key comes first in
+    // the order (probabilities are positive floats, whose bit patterns order as the values do; of
+    // two equal ones the lower index wins).  The list is trusted only while the k-th value in it
+    // lies strictly above the probability of the bound: everything outside the list is at or below
+    // that, so nothing outside can tie with a kept value and claim its place by a lower index.  A
+    // row whose candidates do not fit (long constant stretches), or whose k-th value meets the
+    // bound, takes the general path below.
     {
-      const int nwv = nt >> 6;
-      const int per_wave = tk > 0 ? (tk + nwv - 1) / nwv : 0;
-      if (per_wave >= 1 && per_wave <= 8) {              // (the same for the whole row)
-        float top = 0.f;                                 // weights are >= 0; absent elements weigh 0
-#pragma unroll
-        for (int j = 0; j < VPT; ++j) top = fmaxf(top, pr[j]);
-        float kth = 0.f;
-        for (int r = 0; r < per_wave; ++r) {
-          kth = wave_reduce(top, fmaxop);
-          const unsigned long long holders = __ballot(top == kth);
-          if (lane == __ffsll((long long)holders) - 1) top = -1.0f;   // one lane gives its value up per round
-        }
-        if (lane == 0) s_top_bound[wave] = kth;
-        if (tid == 0) s_cand_n = 0;
-        if (tid < kTopCap) {
-          s_top_rank[tid] = 0;
-          s_top_key[tid] = 0ull;                         // (entries past the list: behind every candidate)
-        }
-        __syncthreads();
-        STAMP(24);
-        float lowest = s_top_bound[0];
-#pragma unroll
-        for (int w = 1; w < kMaxWaves; ++w) lowest = fminf(lowest, s_top_bound[w < nwv ? w : 0]);
-        // Candidates: a wave counts its own (the comparison's lane mask is the ballot: one vector
-        // instruction and a scalar population count per round), reserves its stretch of the list with
-        // one counter update, and goes over the row once more to write them, most rounds finding none.
-        // A candidate is kept as one 64-bit key, probability bits above the complemented index: a
-        // larger key comes first in the order (probabilities are positive floats, whose bit patterns
-        // order as the values do; of two equal ones the lower index wins).
-        int wave_n = 0;
-#pragma unroll
-        for (int j = 0; j < VPT; ++j) wave_n += __popcll(__ballot(pr[j] >= lowest));
-        if (lowest <= 0.f) wave_n = kTopCap + 1;         // fewer than k positive weights: no list
-        int at = 0;
-        if (lane == 0) at = atomicAdd(&s_cand_n, wave_n);
-        at = __builtin_amdgcn_readfirstlane(at);
-        if (wave_n > 0 && at + wave_n <= kTopCap) {
-#pragma unroll
-          for (int j = 0; j < VPT; ++j) {
-            const bool hit = pr[j] >= lowest;
-            const unsigned long long hits = __ballot(hit);
-            if (hits) {                                  // (wave-uniform; one round in four finds anything)
-              // (the empty statement keeps the division and the lane count inside this branch: hoisted
-              // out, as the compiler otherwise does, they run for all 32 elements of every thread)
-              float e = pr[j];
-              asm volatile("" : "+v"(e));
-              const int pos = at + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32),
-                                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u));
-              if (hit)
-                s_top_key[pos] = ((unsigned long long)__builtin_bit_cast(uint32_t, div_shared(e, z, inv_z)) << 32) |
-                                 (uint32_t)~eidx(j);
-              at += __popcll(hits);
-            }
-          }
-        }
-        __syncthreads();
+      if (list_on) {
         const int n = s_cand_n;
+        STAMP(24);
         if (n <= kTopCap) {
+          if (tid < n) {
+            const unsigned long long key = s_top_key[tid];
+            const float q = div_shared(__builtin_bit_cast(float, (uint32_t)(key >> 32)), z, inv_z);
+            s_top_key[tid] = ((unsigned long long)__builtin_bit_cast(uint32_t, q) << 32) | (uint32_t)key;
+          }
+          __syncthreads();
           STAMP(25);
           // Place of every candidate in the descending order = the number of larger keys.  The
           // threads of the workgroup share the comparisons: thread = (candidate, slice of the list).
@@ -636,11 +647,13 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
           }
           __syncthreads();
           STAMP(26);
+          const int nk = min(min(tk, n), kTopK);
+          const float q_kth = __builtin_bit_cast(float, (uint32_t)(s_srt_key[nk - 1] >> 32));
+          if (q_kth > div_shared(exp_nonpos(lowest_x - mx), z, inv_z)) {   // (wave-uniform: see above)
           if (wave != 0) return;
           // Wave 0 alone takes it from here, two ranks per lane (rank = lane, lane + 64), the first
           // nk = min(k, n) of the order.  first = rank of the first copy of the entry's value (equal
           // values are neighbours in the order); above[r] = packed (count | mass) of ranks 0 .. r - 1.
-          const int nk = min(min(tk, n), kTopK);
           const bool live0 = lane < nk, live1 = lane + kWave < nk;
           const unsigned long long k0 = live0 ? s_srt_key[lane] : 0ull, k1 = live1 ? s_srt_key[lane + kWave] : 0ull;
           const float q0 = __builtin_bit_cast(float, (uint32_t)(k0 >> 32)), q1 = __builtin_bit_cast(float, (uint32_t)(k1 >> 32));
@@ -686,6 +699,7 @@ __global__ void __launch_bounds__(NT) sample_kernel(const SampleParams p) {
           }
 #endif
           return;
+          }
         }
       }
     }
