@@ -380,3 +380,45 @@ def test_scheduling_one_step_ahead_gives_every_request_the_same_tokens(seed, pre
     assert got == want
     assert alloc_b.num_free == alloc_a.num_free
     assert len(b.finished) == len(set(id(r) for r in b.finished)) == 20
+
+
+# --- latent (MLA) block cache: host-side bookkeeping, no device needed
+
+def test_paged_mla_cache_blocks_rows_and_release():
+    """PagedMLAKVCache on the CPU: rows of several sequences and layers land in the blocks its tables
+    name (gathering them back gives what was appended, in order), blocks come from -- and return to --
+    the engine's BlockAllocator, a table row is padded with block 0, and running out of blocks raises."""
+    import numpy as np
+    import pytest
+    import torch
+    import mini_mla
+    from mini_vllm import BlockAllocator
+    R, P, bs = 8, 4, 4
+    alloc = BlockAllocator(6, bs)
+    cache = mini_mla.PagedMLAKVCache(6, bs, 2, R, P, 'cpu', dtype=torch.float32, allocator=alloc)
+    rng = np.random.default_rng(0)
+    kept = {}
+
+    def push(seq, layer, n):
+        c = torch.from_numpy(rng.standard_normal((n, R)).astype(np.float32))
+        k = torch.from_numpy(rng.standard_normal((n, P)).astype(np.float32))
+        total = cache.append(seq, layer, c, k)
+        old = kept.get((seq, layer))
+        kept[(seq, layer)] = (c, k) if old is None else (torch.cat((old[0], c)), torch.cat((old[1], k)))
+        assert total == kept[(seq, layer)][0].shape[0] == cache.length(seq, layer)
+
+    push('a', 0, 5); push('a', 1, 5); push('b', 0, 3); push('a', 0, 2); push('a', 1, 2); push('b', 0, 1)
+    assert len(cache.block_tables['a']) == 2 and len(cache.block_tables['b']) == 1 and alloc.num_free == 3
+    tables = cache.tables(['b', 'a'])
+    assert tables.dtype == torch.int32 and tables.shape == (2, 2) and int(tables[0, 1]) == 0
+    for (seq, layer), (c, k) in kept.items():
+        row = tables[['b', 'a'].index(seq)].long()
+        ckv, krope = cache.views(layer)
+        n = c.shape[0]
+        assert torch.equal(ckv[row].reshape(-1, R)[:n], c) and torch.equal(krope[row].reshape(-1, P)[:n], k)
+    with pytest.raises(RuntimeError, match='OOM'):
+        push('c', 0, 4 * bs)                       # needs four blocks, three are free
+    cache.free('c'); cache.free('a'); cache.free('b')
+    assert alloc.num_free == 6 and not cache.block_tables and cache.length('a', 0) == 0
+    with pytest.raises(ValueError):
+        mini_mla.PagedMLAKVCache(4, 6, 1, R, P, 'cpu')

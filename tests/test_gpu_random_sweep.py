@@ -170,6 +170,23 @@ def test_mla_decode_random_shapes(ops, device, seed):
     out = ops.mla_decode(q.to(device), c_kv.to(device), k_rope.to(device), torch.from_numpy(cos).to(device),
                          torch.from_numpy(sin).to(device), torch.from_numpy(ctx).to(device), max_ctx, scale)
     np.testing.assert_allclose(out.cpu().numpy(), want, err_msg=f'H{H} R{R} P{P} ctx {ctx.tolist()}', **MLA_TOL[dtype])
+    # the same rows scattered into blocks of a pool (block size and layout drawn too): the block-table
+    # call returns the dense call's bits
+    bs = int(rng.choice([1, 2, 8, 16, 64]))
+    per = (S + bs - 1) // bs
+    NB = seqs * per + 2
+    bt = rng.permutation(NB)[:seqs * per].reshape(seqs, per).astype(np.int32)
+    split = bool(rng.integers(0, 2))                     # a pool each for c_kv / k_rope, or one pool of R + P wide rows
+    rows = torch.cat((c_kv, k_rope), dim=-1)
+    rows = torch.nn.functional.pad(rows, (0, 0, 0, per * bs - S)).view(seqs * per, bs, R + P)
+    pool = torch.full((NB, bs, R + P), float('nan'), dtype=dtype)
+    pool[torch.from_numpy(bt.reshape(-1).astype(np.int64))] = rows
+    pool = pool.to(device)
+    pools = (pool[..., :R].contiguous(), pool[..., R:].contiguous()) if split else (pool[..., :R], pool[..., R:])
+    paged = ops.mla_decode_paged(q.to(device), pools[0], pools[1], torch.from_numpy(bt).to(device),
+                                 torch.from_numpy(cos).to(device), torch.from_numpy(sin).to(device),
+                                 torch.from_numpy(ctx).to(device), max_ctx, scale)
+    assert torch.equal(paged.view(torch.int32), out.view(torch.int32)), f'H{H} R{R} P{P} block {bs} split {split}'
 
 
 @pytest.mark.parametrize('seed', range(40))
