@@ -5,7 +5,10 @@ odd block sizes).  These sweeps draw every dimension at random -- batch, head gr
 head_dim, block size, context lengths (zero included), dtype, cache layout -- so that
 combinations nobody thought of still meet the oracle.  Each draw is small enough for the
 oracle to finish in well under a second; seeds are fixed, so a failure names its case.
+MI355_SWEEP_SCALE=n draws n times as many cases per sweep (a longer hunt, run by hand; the suite runs 1).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -17,6 +20,10 @@ pytestmark = pytest.mark.gpu
 LOWP_TOL = dict(atol=1e-2, rtol=1.6e-2)
 F32_TOL = dict(atol=1e-5, rtol=1e-5)
 DTYPES = [torch.float32, torch.bfloat16, torch.float16]
+
+
+def _seeds(n):
+    return range(n * max(1, int(os.environ.get('MI355_SWEEP_SCALE', '1'))))
 
 
 @pytest.fixture(scope='module')
@@ -35,7 +42,7 @@ def _head_grouping(rng):
     return hkv * group, hkv
 
 
-@pytest.mark.parametrize('seed', range(48))
+@pytest.mark.parametrize('seed', _seeds(48))
 def test_decode_random_shapes(ops, device, seed):
     rng = np.random.default_rng(1000 + seed)
     dtype = DTYPES[seed % 3]
@@ -69,7 +76,7 @@ def test_decode_random_shapes(ops, device, seed):
         np.testing.assert_allclose(got[b], want, err_msg=f'row {b} ctx {ctx[b]} {Hq}/{Hkv} D{D} BS{BS} {layout}', **tol)
 
 
-@pytest.mark.parametrize('seed', range(24))
+@pytest.mark.parametrize('seed', _seeds(24))
 def test_paged_prefill_random_segments(ops, device, seed):
     """Chunks of new tokens behind cached prefixes of random length; both the decode-shaped
     kernel (short chunks) and the flash-attention kernel in paged mode (48 tokens and up)."""
@@ -120,7 +127,7 @@ def test_paged_prefill_random_segments(ops, device, seed):
     assert np.isfinite(got[owned]).all()
 
 
-@pytest.mark.parametrize('seed', range(24))
+@pytest.mark.parametrize('seed', _seeds(24))
 def test_prefill_causal_random_packing(ops, device, seed):
     """Packed variable-length prompts: fp32 runs the VALU kernel, 16-bit at head_dim 64 / 128 the
     matrix-core kernel, 16-bit at other head dims the VALU kernel again."""
@@ -146,7 +153,7 @@ def test_prefill_causal_random_packing(ops, device, seed):
 MLA_TOL = {torch.bfloat16: dict(atol=1e-2, rtol=1.6e-2), torch.float16: dict(atol=2e-3, rtol=4e-3)}
 
 
-@pytest.mark.parametrize('seed', range(24))
+@pytest.mark.parametrize('seed', _seeds(24))
 def test_mla_decode_random_shapes(ops, device, seed):
     """Latent-KV attention: kv_lora_rank, rope width, head count (both the 16-heads-per-workgroup
     and the 64-heads-per-workgroup kernels) and ragged contexts drawn at random."""
@@ -189,7 +196,7 @@ def test_mla_decode_random_shapes(ops, device, seed):
     assert torch.equal(paged.view(torch.int32), out.view(torch.int32)), f'H{H} R{R} P{P} block {bs} split {split}'
 
 
-@pytest.mark.parametrize('seed', range(40))
+@pytest.mark.parametrize('seed', _seeds(40))
 def test_sampler_random_rows(ops, device, seed):
     """Greedy ids exact and the kept set / renormalised probabilities of the temperature, top-p and
     top-k filters against the sorting oracle, for random vocabulary sizes, row counts and settings."""
@@ -212,7 +219,20 @@ def test_sampler_random_rows(ops, device, seed):
         # only the token whose running mass lands within float rounding of top_p may differ; entries whose
         # probability underflows float32 (peaked rows at low temperature) are "kept" with probability 0
         diff = np.nonzero((got_kept != kept) & (np.maximum(want, probs[b]) > 1e-30))[0]
-        assert len(diff) <= 1, f'row {b} vocab {vocab} T{temps[b]} p{top_ps[b]} k{top_ks[b]}: kept sets differ at {diff}'
+        if len(diff) > 1:
+            # A flat row of a large vocabulary under a cut close to 1 keeps tens of thousands of entries of ~1e-6
+            # each: the oracle's float32 running sum (the reference's, 05_mini_vllm/mini_vllm.py:621) is then only
+            # good to ~1e-5 of mass, the kernel's sums are exact.  Entries may differ only where the mass above
+            # them, summed in float64 over the float32 probabilities, lies that close to top_p.
+            x = logits[b] / np.float32(temps[b])
+            e = np.exp(x - x.max(), dtype=np.float32)
+            p64 = (e / e.sum(dtype=np.float32)).astype(np.float64)
+            order = np.argsort(-p64, kind='stable')
+            above = np.empty(vocab)
+            above[order] = np.cumsum(p64[order]) - p64[order]
+            assert top_ks[b] == 0 and np.all(np.abs(above[diff] - top_ps[b]) < 3e-5), \
+                f'row {b} vocab {vocab} T{temps[b]} p{top_ps[b]} k{top_ks[b]}: kept sets differ at {diff}'
+            continue
         if len(diff) == 0:
             np.testing.assert_allclose(probs[b], want, rtol=2e-4, atol=1e-7)
         assert got_kept[int(ids[b])]
@@ -253,7 +273,7 @@ def _serve(mv, seed, graphs, lookahead):
     return eng, [outs.get(rid, []) for rid in ids], max_new
 
 
-@pytest.mark.parametrize('seed', range(10))
+@pytest.mark.parametrize('seed', _seeds(10))
 def test_engine_random_serving_runs(device, seed):
     """Requests that arrive while others run, more requests than sequence slots, token budgets that
     chunk the prompts, shared prefixes with and without prefix caching: the engine that replays
@@ -282,7 +302,7 @@ def _rotate_half(x):
     return torch.cat((-hi, lo), dim=-1)
 
 
-@pytest.mark.parametrize('seed', range(18))
+@pytest.mark.parametrize('seed', _seeds(18))
 def test_layer_steps_random_shapes(ops, device, seed):
     """RMSNorm (+ carried residual), the SwiGLU gate and RoPE + KV write on randomly drawn widths, row
     counts, head geometries, block sizes and cache layouts, against the torch expressions."""
