@@ -40,6 +40,7 @@ enum Knob {
   kKnobPagedBalanceWgs,   // MI355_PAGED_BALANCE_WGS   workgroups a decode launch spreads its kv heads over for ragged batches (0: off)
   kKnobDpExchangeProbe,   // MI355_DP_EXCHANGE_PROBE   measurement only, bit mask: 1 no collective, 2 no completion event, 4 no watcher
   kKnobMlaRowGroups,      // MI355_MLA_ROW_GROUPS      1: paged rank-512 MLA tiles staged as 8 consecutive rows per wave
+  kKnobMlaWide,           // MI355_MLA_WIDE            1: 128 heads per MLA workgroup above 64 heads (rank 512, rope 64)
   kKnobCount
 };
 int knob(Knob k);
@@ -70,6 +71,11 @@ int mla_f32_launch(float* out, const float* q, int64_t q_stride_row, const float
                    const int32_t* block_tables = nullptr, int block_size = 0, int max_blocks = 0, int num_blocks = 0,
                    int64_t ckv_stride_blk = 0, int64_t krope_stride_blk = 0);
 void mla_f32_plan(int rows, int H, int max_context, int* nsplit, int* tps, size_t* ws_bytes, int R);
+// 128 heads per workgroup on the 32 x 32 x 16 matrix instruction (mla_decode_wide.hip): kv_lora_rank 512,
+// rope 64, more than 64 heads, 16-bit dtypes.  `params` is the MlaParams block of mla_common.h.
+bool mla_wide_supported(int H, int R, int P, int dtype);
+int mla_wide_max_paged_tokens(int block_size);
+int mla_wide_launch(const void* params, int dtype, bool paged, hipStream_t stream);
 // Combines token-split partials [rows, H, nsplit, R] + (max, sum) records into out (mla_decode.hip).
 int mla_merge_launch(float* out, float* ws_acc, float* ws_ml, const int32_t* ctx, int rows, int H, int R,
                      int max_ctx, int nsplit, int tps, hipStream_t stream);

@@ -25,46 +25,10 @@
 #include <type_traits>
 
 #include "common.h"
+#include "mla_common.h"
 
 namespace mi355 {
 namespace {
-
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-
-constexpr int kTok = 16;        // tokens per step (one-wave kernel)
-constexpr int kTok2 = 32;       // tokens per step (four-wave kernel)
-constexpr int kHeadTile = 16;   // heads per workgroup
-
-struct MlaParams {
-  float* out;            // [rows, H, R] fp32
-  const void* q;         // [rows, H, R + P]
-  const void* ckv;       // c_kv rows
-  const void* krope;     // k_rope rows (un-rotated)
-  const float* cos_t;    // [table_len, P]
-  const float* sin_t;
-  const int32_t* ctx;    // [rows]
-  const int32_t* row_seq;  // [rows] cache sequence of each query row, or null (= row)
-  float* ws_acc;         // [rows, H, nsplit, R]
-  float* ws_ml;          // [rows, H, nsplit, 2]
-  int64_t q_stride_row, ckv_stride_seq, ckv_stride_tok, krope_stride_seq, krope_stride_tok;
-  int rows, H, P, table_len, max_ctx, n_ht, nsplit, tps;
-  float scale_log2e;
-  // Paged caches (the PAGED instantiations): token t of sequence s sits in block bt[s][t >> bs_shift]
-  // (clamped to the pool) at row t & bs_mask; *_stride_seq are then unused.
-  const int32_t* bt = nullptr;   // [sequences, max_blocks]
-  int64_t ckv_stride_blk = 0, krope_stride_blk = 0;
-  int bs_shift = 0, bs_mask = 0, max_blocks = 0, num_blocks = 0;
-};
-
-// Addressing modes of the kernels below (template parameter PAGED).
-constexpr int kDense = 0;        // rows of one sequence at a fixed stride from the sequence's base
-constexpr int kPaged = 1;        // rows in blocks named by a block table, any power-of-two block size
-constexpr int kPagedGroups = 2;  // ... blocks of >= 8 tokens, kv_lora_rank 512, rope slot 64: see GroupAt
-constexpr bool is_paged(int mode) { return mode == kPaged || mode == kPagedGroups; }
-constexpr bool is_grouped(int mode) { return mode == kPagedGroups; }
 
 // Element offset of token `tok`'s row from the cache base: dense rows of one sequence (the base
 // already points at the sequence), or a row of the block the sequence's table names.
@@ -902,6 +866,7 @@ __global__ void __launch_bounds__(256) mla_merge_kernel(const MlaParams p) {
 
 struct MlaPlan {
   bool many;
+  bool wide;   // 128 heads per workgroup (mla_decode_wide.hip)
   int n_ht, nsplit, tps;
   size_t ws_bytes;
 };
@@ -916,7 +881,8 @@ int mla_plan(int rows, int H, int R, int P, int max_context, int dtype, MlaPlan*
   if (max_context < 0) return fail(MI355_EINVAL, "mla_decode: max_context %d", max_context);
   MlaPlan pl;
   pl.many = R >= 128 && H > kHeadTile && knob(kKnobMlaManyHeads) != 0;   // 64 heads per workgroup
-  pl.n_ht = pl.many ? (H + 4 * kHeadTile - 1) / (4 * kHeadTile) : (H + kHeadTile - 1) / kHeadTile;
+  pl.wide = pl.many && mla_wide_supported(H, R, P, dtype) && knob(kKnobMlaWide) != 0;
+  pl.n_ht = pl.wide ? (H + 127) / 128 : pl.many ? (H + 4 * kHeadTile - 1) / (4 * kHeadTile) : (H + kHeadTile - 1) / kHeadTile;
   const int ctx = max_context > 0 ? max_context : 1;
   const int64_t base = (int64_t)rows * pl.n_ht;
   // one-wave kernel (R < 128): 8 workgroups per CU.  Four-wave kernel: one workgroup per CU
@@ -944,6 +910,11 @@ int launch_tail(const MlaParams& p, hipStream_t s) {
     return check_launch("mla_merge_kernel");
   }
   return 0;
+}
+
+int launch_wide_then_merge(const MlaParams& p, int R, int dtype, bool paged, hipStream_t s) {
+  if (int rc = mla_wide_launch(&p, dtype, paged, s)) return rc;
+  return R == 512 ? launch_tail<512>(p, s) : fail(MI355_EUNSUPPORTED, "mla_decode: wide kernel at rank %d", R);
 }
 
 template <class Tag, int R, int PAGED>
@@ -1120,8 +1091,16 @@ int mla_decode_impl(const char* what, float* out, const void* q, int64_t q_strid
     p.bs_mask = pg.block_size - 1;
     p.max_blocks = pg.max_blocks;
     p.num_blocks = pg.num_blocks;
+    if (pl.wide) {
+      // the wide kernel holds its token range's block ids in LDS; a longer range (tiny blocks) goes to
+      // the 64-head kernel, with the same token splits and so the same workspace
+      if (p.tps < mla_wide_max_paged_tokens(pg.block_size) && ckv_stride_tok < (1 << 26) && krope_stride_tok < (1 << 26))
+        return launch_wide_then_merge(p, R, dtype, true, s);
+      p.n_ht = (H + 4 * kHeadTile - 1) / (4 * kHeadTile);
+    }
     return dtype == MI355_BF16 ? launch_t<BF16, kPaged>(R, p, pl.many, s) : launch_t<F16, kPaged>(R, p, pl.many, s);
   }
+  if (pl.wide) return launch_wide_then_merge(p, R, dtype, false, s);
   return dtype == MI355_BF16 ? launch_t<BF16, kDense>(R, p, pl.many, s) : launch_t<F16, kDense>(R, p, pl.many, s);
 }
 }  // namespace
