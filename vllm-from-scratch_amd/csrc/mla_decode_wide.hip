@@ -75,6 +75,15 @@ __device__ __forceinline__ void score_mma(f32x16& acc, u32x4 a, u32x4 b) {
   }
 }
 
+#ifndef WIDE_KO
+#define WIDE_KO 0   // timing-only side builds: bit mask of parts left out (results are wrong)
+#endif
+#ifndef WIDE_KA
+#define WIDE_KA 4
+#endif
+#ifndef WIDE_KAV
+#define WIDE_KAV 4
+#endif
 constexpr int kR = 512, kP = 64;          // the one shape this kernel serves
 constexpr int kTile = 32;                 // tokens per tile
 constexpr int kKS = (kR + kP) / 16;       // k-steps of the score product (36)
@@ -107,6 +116,7 @@ typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
 //   to_lds16_rows: every lane reads base + voff (base wave-uniform, in SGPRs)
 //   to_lds16_lanes: every lane reads its own 64-bit address
 __device__ __forceinline__ void to_lds16_rows(const void* base, uint32_t voff, uint32_t dst) {
+  if (WIDE_KO & 16) return;
   uint32_t keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep)
@@ -114,6 +124,7 @@ __device__ __forceinline__ void to_lds16_rows(const void* base, uint32_t voff, u
                : "memory");
 }
 __device__ __forceinline__ void to_lds16_lanes(const void* src, uint32_t dst) {
+  if (WIDE_KO & 16) return;
   uint32_t keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep)
@@ -203,10 +214,10 @@ __global__ void __launch_bounds__(256) mla_decode_kernel_wide(const MlaParams p)
   const int rr = 8 * wave + (lane >> 3);             // the rope row this lane fetches and rotates
   const int rslot = lane & 7, rswz = (rr >> 1) & 7;
   const uint32_t lds0 = (uint32_t)(uintptr_t)lds;   // LDS byte address of the image
-  auto issue_tile = [&](int t0, int bufoff) {
+  // piece i of a tile's loads: 0 .. 7 the wave's c_kv rows, 8 its rope rows, 9 / 10 their cos / sin rows
+  auto issue_piece = [&](int i, int t0, int bufoff) __attribute__((always_inline)) {
     const int last = t_end - 1;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    if (i < 8) {
       const int r = wave + 4 * i;
       const int tok = min(t0 + r, last);                 // wave-uniform
       const char* src;
@@ -217,19 +228,27 @@ __global__ void __launch_bounds__(256) mla_decode_kernel_wide(const MlaParams p)
         src = ckv + (uint32_t)(tok * cstride2);
       }
       to_lds16_rows(src, lane * 16, __builtin_amdgcn_readfirstlane(lds0 + bufoff + row_off(r)));
+      return;
     }
     const int tokr = min(t0 + rr, last);
-    const char* rsrc;
-    if constexpr (is_paged(PAGED)) {
-      const int id = *(const __attribute__((address_space(3))) int*)(lds + kIdsOff + 4 * ((tokr >> p.bs_shift) - blk0));
-      rsrc = krope + ((int64_t)id * p.krope_stride_blk * 2 + (int64_t)(tokr & p.bs_mask) * rstride2);
-    } else {
-      rsrc = krope + (uint32_t)(tokr * rstride2);
+    if (i == 8) {
+      const char* rsrc;
+      if constexpr (is_paged(PAGED)) {
+        const int id = *(const __attribute__((address_space(3))) int*)(lds + kIdsOff + 4 * ((tokr >> p.bs_shift) - blk0));
+        rsrc = krope + ((int64_t)id * p.krope_stride_blk * 2 + (int64_t)(tokr & p.bs_mask) * rstride2);
+      } else {
+        rsrc = krope + (uint32_t)(tokr * rstride2);
+      }
+      to_lds16_lanes(rsrc + ((rslot ^ rswz) << 4), __builtin_amdgcn_readfirstlane(lds0 + bufoff + kRopeOff + wave * 1024));
+      return;
     }
-    to_lds16_lanes(rsrc + ((rslot ^ rswz) << 4), __builtin_amdgcn_readfirstlane(lds0 + bufoff + kRopeOff + wave * 1024));
     const int pos = min(tokr, p.table_len - 1);
-    to_lds16_lanes(p.cos_t + (int64_t)pos * kP + 4 * rslot, __builtin_amdgcn_readfirstlane(lds0 + bufoff + kCosOff + wave * 1024));
-    to_lds16_lanes(p.sin_t + (int64_t)pos * kP + 4 * rslot, __builtin_amdgcn_readfirstlane(lds0 + bufoff + kSinOff + wave * 1024));
+    if (i == 9) to_lds16_lanes(p.cos_t + (int64_t)pos * kP + 4 * rslot, __builtin_amdgcn_readfirstlane(lds0 + bufoff + kCosOff + wave * 1024));
+    else to_lds16_lanes(p.sin_t + (int64_t)pos * kP + 4 * rslot, __builtin_amdgcn_readfirstlane(lds0 + bufoff + kSinOff + wave * 1024));
+  };
+  auto issue_tile = [&](int t0, int bufoff) {
+#pragma unroll
+    for (int i = 0; i < kLoadsPerTile; ++i) issue_piece(i, t0, bufoff);
   };
 
   // Rotation of this lane's four (lo, hi) pairs of rope row rr: dims 4 rslot .. + 4 and their
@@ -264,12 +283,18 @@ __global__ void __launch_bounds__(256) mla_decode_kernel_wide(const MlaParams p)
   const int grp = (lane >> 4) & 1, qi = (lane & 15) >> 2, pi = lane & 3;
   const int v_lane = (4 * h + qi) * kPitch + h * 16 + (16 * grp + 4 * pi) * 2;   // V^T operand
 
-  auto compute = [&](int t0, int bufoff) {
+  // One tile of a live wave, in the order the instructions should issue (the asm statements keep
+  // their order): the score product with the loads of tile t + 2 dealt out between its matrix
+  // instructions; maximum and the first half of the weights; the first half of the value product
+  // with the second half of the weights in its shadow; the second half of the value product with,
+  // in its shadow, the wait for this wave's loads of tile t + 1 and the rotation of their rope rows.
+  auto tile_step = [&](int t0, int bufoff, int next_t0, int next2_t0, int bufoff_next, int bufoff_next2) {
     // ---- S^T = K . Q^T
     f32x16 st;
     {
-      constexpr int kAhead = 4;
+      constexpr int kAhead = WIDE_KA;
       auto a_at = [&](int n) __attribute__((always_inline)) {
+        if (WIDE_KO & 2) return u32x4{(uint32_t)lane, 0u, 0u, 0u};
         if (n < kR / 16) return *(const __attribute__((address_space(3))) u32x4*)(lds + bufoff + k_lane + 32 * n);
         return *(const __attribute__((address_space(3))) u32x4*)(lds + bufoff + kr_lane + (((2 * (n - kR / 16) + h) ^ kr_swz) << 4));
       };
@@ -280,9 +305,13 @@ __global__ void __launch_bounds__(256) mla_decode_kernel_wide(const MlaParams p)
       for (int n = 0; n < kKS; ++n) {
         const u32x4 a = abuf[n % kAhead];
         if (n + kAhead < kKS) abuf[n % kAhead] = a_at(n + kAhead);
-        if (n == 0) score_mma<Tag, true, false>(st, a, qf[n]);
+        if (WIDE_KO & 1) {
+          if (n == 0) st = f32x16(0.f);
+          asm volatile("" ::"v"(a));
+        } else if (n == 0) score_mma<Tag, true, false>(st, a, qf[n]);
         else if (n == kKS - 1) score_mma<Tag, false, true>(st, a, qf[n]);
         else score_mma<Tag, false, false>(st, a, qf[n]);
+        if (n % 3 == 1 && n / 3 < kLoadsPerTile) issue_piece(n / 3, next2_t0, bufoff_next2);
       }
     }
     // ---- online softmax; register i of lane (c, h) is token t0 + 8 (i / 4) + 4 h + i % 4 of head c
@@ -313,61 +342,82 @@ __global__ void __launch_bounds__(256) mla_decode_kernel_wide(const MlaParams p)
 #pragma unroll
       for (int i = 0; i < kDB; ++i) scale_acc(o[i], f);
     }
-    float ps = 0.f;
+    // ---- O^T += V^T . P^T.  k-slot j of lane half h in step u is token 16 u + 8 (j / 4) + 4 h + j % 4:
+    // registers 8 u .. 8 u + 7 of P as they stand, two transposing 4-token reads of V.
+    constexpr int NV = 2 * kDB, kAheadV = WIDE_KAV;
+    auto v_at = [&](int n) __attribute__((always_inline)) {   // n-th operand: step u = n / kDB, dim block n % kDB
+      if (WIDE_KO & 8) return u32x4{(uint32_t)lane, 0u, 0u, 0u};
+      const int off = bufoff + v_lane + (16 * (n / kDB)) * kPitch + (n % kDB) * 64;
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + off));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) s16x4*)(lds + off + 8 * kPitch + 32));
+      const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
+      return u32x4{lo2[0], lo2[1], hi2[0], hi2[1]};
+    };
+    u32x4 vbuf[kAheadV];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int n = 0; n < kAheadV; ++n) vbuf[n] = v_at(n);
+    float ps = 0.f;
+    u32x4 pb[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
       st[i] = fast_exp2(st[i] - m_run);
       ps += st[i];
     }
-    l_run += ps;
-    // ---- O^T += V^T . P^T.  k-slot j of lane half h in step u is token 16 u + 8 (j / 4) + 4 h + j % 4:
-    // registers 8 u .. 8 u + 7 of P as they stand, two transposing 4-token reads of V.
-    u32x4 pb[2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int w = 0; w < 4; ++w) pb[0][w] = Mma32<Tag>::pack2(st[2 * w], st[2 * w + 1]);
+    asm volatile("s_nop 3");   // the packed weights come straight from the VALU; the compiler does not see their consumer
 #pragma unroll
-      for (int w = 0; w < 4; ++w) pb[u][w] = Mma32<Tag>::pack2(st[8 * u + 2 * w], st[8 * u + 2 * w + 1]);
-    {
-      constexpr int NV = 2 * kDB, kAhead = 4;
-      auto v_at = [&](int n) __attribute__((always_inline)) {   // n-th operand: step u = n / kDB, dim block n % kDB
-        const int off = bufoff + v_lane + (16 * (n / kDB)) * kPitch + (n % kDB) * 64;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + off));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(lds + off + 8 * kPitch + 32));
-        const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
-        return u32x4{lo2[0], lo2[1], hi2[0], hi2[1]};
-      };
-      u32x4 vbuf[kAhead];
-      asm volatile("s_nop 3");   // the packed weights come straight from the VALU; the compiler does not see their consumer
+    for (int n = 0; n < NV; ++n) {
+      const u32x4 va = vbuf[n % kAheadV];
+      if (n + kAheadV < NV) vbuf[n % kAheadV] = v_at(n + kAheadV);
+      if (WIDE_KO & 4) asm volatile("" ::"v"(va), "v"(pb[n / kDB]));
+      else out_mma<Tag>(o[n % kDB], va, pb[n / kDB]);
+      if (n < 8) {   // the second half of the weights, two per matrix instruction of the first half
+        st[8 + n] = fast_exp2(st[8 + n] - m_run);
+        ps += st[8 + n];
+      }
+      if (n == 9) {
 #pragma unroll
-      for (int n = 0; n < kAhead; ++n) vbuf[n] = v_at(n);
-#pragma unroll
-      for (int n = 0; n < NV; ++n) {
-        const u32x4 va = vbuf[n % kAhead];
-        if (n + kAhead < NV) vbuf[n % kAhead] = v_at(n + kAhead);
-        out_mma<Tag>(o[n % kDB], va, pb[n / kDB]);
+        for (int w = 0; w < 4; ++w) pb[1][w] = Mma32<Tag>::pack2(st[8 + 2 * w], st[8 + 2 * w + 1]);
+        l_run += ps;
+      }
+      if (n == kDB - 1) asm volatile("s_nop 1");
+      if (n == kDB + 1) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLoadsPerTile) : "memory");
+        rotate(bufoff_next);
       }
     }
+    (void)next_t0;
   };
 
-  // Tile t lives in buffer t mod 3.  Per tile: wait for this wave's own loads of tile t (those of
-  // tile t + 1 stay in flight), rotate the rope rows this wave fetched, barrier (everybody's part
-  // of tile t is in LDS; everybody is done reading tile t - 1), refill tile t - 1's buffer with
-  // tile t + 2, compute.  Loads past the last tile are issued all the same (clamped to the last
-  // row) so that the count of loads in flight is the same at every wait.
+  // Tile t lives in buffer t mod 3.  A tile's loads go out two tiles ahead (during tile t - 2's
+  // score product), are waited for by the wave that issued them one tile ahead (which then rotates
+  // the rope rows among them), and the barrier at the top of tile t makes everybody's part visible
+  // to everybody -- and says that everybody is done reading tile t - 1, whose buffer the loads of
+  // tile t + 2 then overwrite.  Loads past the last tile are issued all the same (clamped to the
+  // last row), so that the count of loads in flight is the same at every wait.
   if (ntiles > 0) {
     issue_tile(t_begin, 0);
     issue_tile(t_begin + kTile, kBufBytes);
-    int cur = 0, nxt2 = 2 * kBufBytes;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLoadsPerTile) : "memory");
+    rotate(0);
+    int cur = 0, nxt = kBufBytes, nxt2 = 2 * kBufBytes;
     for (int t = 0; t < ntiles; ++t) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLoadsPerTile) : "memory");
-      rotate(cur);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      issue_tile(t_begin + (t + 2) * kTile, nxt2);
-      if (wave_live) compute(t_begin + t * kTile, cur);
-      nxt2 = cur;
-      cur = cur == 2 * kBufBytes ? 0 : cur + kBufBytes;
+      const int t0 = t_begin + t * kTile;
+      if (wave_live) {
+        tile_step(t0, cur, t0 + kTile, t0 + 2 * kTile, nxt, nxt2);
+      } else {   // a wave without heads only stages
+        issue_tile(t0 + 2 * kTile, nxt2);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLoadsPerTile) : "memory");
+        rotate(nxt);
+      }
+      const int c0 = cur;
+      cur = nxt;
+      nxt = nxt2;
+      nxt2 = c0;
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 3" ::: "memory");   // (+ the last matrix results are readable)
   }
