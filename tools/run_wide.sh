@@ -2,7 +2,7 @@
 # Tests of the 128-heads-per-workgroup MLA kernel, then its timing beside the 64-head kernel's.
 # Usage (on the GPU box, from the repository root): bash tools/run_wide.sh <tag> [test file]
 tag=${1:-w}
-tests=${2:-wip_mla_wide.py}
+tests=${2:-"test_gpu_mla.py -k wide"}
 out=gpurun_out/r3w
 mkdir -p $out
 (cd tests && timeout -k 10 400 python -u -m pytest $tests -x -q --timeout 120 --timeout-method thread) > $out/t_$tag.log 2>&1

@@ -1091,16 +1091,17 @@ int mla_decode_impl(const char* what, float* out, const void* q, int64_t q_strid
     p.bs_mask = pg.block_size - 1;
     p.max_blocks = pg.max_blocks;
     p.num_blocks = pg.num_blocks;
-    if (pl.wide) {
-      // the wide kernel holds its token range's block ids in LDS; a longer range (tiny blocks) goes to
-      // the 64-head kernel, with the same token splits and so the same workspace
-      if (p.tps < mla_wide_max_paged_tokens(pg.block_size) && ckv_stride_tok < (1 << 26) && krope_stride_tok < (1 << 26))
-        return launch_wide_then_merge(p, R, dtype, true, s);
-      p.n_ht = (H + 4 * kHeadTile - 1) / (4 * kHeadTile);
-    }
+    // The wide kernel holds its token range's block ids in LDS and takes its row maxima on the
+    // unscaled scores; a longer range (tiny blocks) or a scale that is not positive goes to the
+    // 64-head kernel, with the same token splits and so the same workspace.
+    if (pl.wide && scale > 0.f && p.tps < mla_wide_max_paged_tokens(pg.block_size) && ckv_stride_tok < (1 << 26) &&
+        krope_stride_tok < (1 << 26))
+      return launch_wide_then_merge(p, R, dtype, true, s);
+    if (pl.wide) p.n_ht = (H + 4 * kHeadTile - 1) / (4 * kHeadTile);
     return dtype == MI355_BF16 ? launch_t<BF16, kPaged>(R, p, pl.many, s) : launch_t<F16, kPaged>(R, p, pl.many, s);
   }
-  if (pl.wide) return launch_wide_then_merge(p, R, dtype, false, s);
+  if (pl.wide && scale > 0.f) return launch_wide_then_merge(p, R, dtype, false, s);
+  if (pl.wide) p.n_ht = (H + 4 * kHeadTile - 1) / (4 * kHeadTile);
   return dtype == MI355_BF16 ? launch_t<BF16, kDense>(R, p, pl.many, s) : launch_t<F16, kDense>(R, p, pl.many, s);
 }
 }  // namespace

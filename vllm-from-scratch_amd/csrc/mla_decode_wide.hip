@@ -14,10 +14,12 @@
 //   reads of the same rows: an LDS operand feeds twice the flops it does in the 16 x 16 form.
 //
 // With every register taken nothing can be staged through registers, so the cached rows travel
-// global -> LDS directly (global_load_lds_dwordx4), two 32-token tiles ahead, into three buffers;
-// the cos / sin rows of the tile's positions take the same road, which keeps ordinary loads (whose
-// waits would drain the prefetch) out of the loop.  A wave rotates the rope part of the eight rows
-// it fetched itself, behind its own wait and ahead of the tile's one barrier.
+// global -> LDS directly (global_load_lds_dwordx4), two 32-token tiles ahead, into four buffers.
+// One wave per SIMD also means that nothing but the wave's own instruction stream can keep the
+// matrix pipe busy, so the tiles are software-pipelined: while the score product of tile t + 1
+// runs, the wave does the softmax arithmetic of tile t between its matrix instructions (and issues
+// the loads of tile t + 3); while the value product of tile t runs, it waits for its own loads of
+// tile t + 2 and rotates the rope part of the eight rows among them.  One barrier per tile.
 #include <type_traits>
 
 #include "common.h"
@@ -78,11 +80,17 @@ __device__ __forceinline__ void score_mma(f32x16& acc, u32x4 a, u32x4 b) {
 #ifndef WIDE_KO
 #define WIDE_KO 0   // timing-only side builds: bit mask of parts left out (results are wrong)
 #endif
-#ifndef WIDE_KA
-#define WIDE_KA 4
+#ifndef WIDE_TIMING
+#define WIDE_TIMING 0
 #endif
-#ifndef WIDE_KAV
-#define WIDE_KAV 4
+#ifndef WIDE_PACKED
+#define WIDE_PACKED 0
+#endif
+#ifndef WIDE_KG
+#define WIDE_KG 3    // LDS operands per group of the score product (two groups in flight)
+#endif
+#ifndef WIDE_KGV
+#define WIDE_KGV 2   // ... of the value product
 #endif
 constexpr int kR = 512, kP = 64;          // the one shape this kernel serves
 constexpr int kTile = 32;                 // tokens per tile
@@ -95,41 +103,59 @@ constexpr int kDB = kR / 32;              // 32-dim blocks of the latent output 
 // direct-to-LDS load writes 1 KiB contiguously: eight rows' rope parts, or one row's c_kv.
 constexpr int kPitch = 1088;
 constexpr int kRopeOff = kTile * kPitch + 64;         // 34880
-constexpr int kCosOff = kRopeOff + kTile * 128;
-constexpr int kSinOff = kCosOff + kTile * 128;
-constexpr int kBufBytes = kSinOff + kTile * 128;      // 47168
-constexpr int kBuffers = 3;
+constexpr int kBufBytes = kRopeOff + kTile * 128;     // 38976
+constexpr int kBuffers = 4;
 constexpr int kIdsOff = kBuffers * kBufBytes;         // block ids of the workgroup's token range (paged caches)
-constexpr int kIdsMax = 4096;
-constexpr int kLoadsPerTile = 8 + 3;                  // direct-to-LDS loads a wave issues per tile
+constexpr int kIdsMax = (160 * 1024 - kIdsOff) / 4;   // 1984: what is left of the CU's 160 KiB
+constexpr int kLdsLoads = 8 + 1;                      // direct-to-LDS loads a wave issues per tile: 8 c_kv rows, 1 KiB of rope parts
 
 __device__ __forceinline__ constexpr int row_off(int r) { return r * kPitch + ((r >> 2) & 3) * 16; }
 
 typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
 
+// f(integral_constant<int, B>), ..., f(integral_constant<int, E - 1>): a loop whose index is a
+// compile-time constant in the body (the pieces dealt out between matrix instructions are chosen
+// by it; `#pragma unroll` leaves that to the optimiser, which gave up on the larger bodies).
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
 // Direct-to-LDS loads: 64 lanes x 16 bytes from global memory to 1 KiB of LDS at byte address `dst`
 // (wave-uniform).  Written as asm: given the builtin, the compiler waits for EVERY such load in
 // flight (vmcnt(0)) before the next LDS read it cannot prove independent, which would drain the two
 // tiles of prefetch on every tile.  The compiler therefore does not count these loads either; the
-// kernel waits for them itself (s_waitcnt vmcnt(N) below).  M0 carries the LDS address and is put
-// back, since the compiler does not expect a statement to change it.
-//   to_lds16_rows: every lane reads base + voff (base wave-uniform, in SGPRs)
+// kernel waits for them itself (s_waitcnt vmcnt(N) below).
+//   to_lds16_rows: every lane reads base + voff (base wave-uniform, in SGPRs); LDS address dst + DST_CONST
 //   to_lds16_lanes: every lane reads its own 64-bit address
+// M0 carries the LDS address.  It is written and left: nothing the compiler generates for this
+// kernel uses M0 (it would set it itself before a use of its own).
+template <int DST_CONST>
 __device__ __forceinline__ void to_lds16_rows(const void* base, uint32_t voff, uint32_t dst) {
   if (WIDE_KO & 16) return;
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(voff), "s"(base), "s"(dst)
-               : "memory");
+  asm volatile("s_add_i32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               :
+               : "v"(voff), "s"(base), "s"(dst), "n"(DST_CONST)
+               : "memory", "scc");
 }
 __device__ __forceinline__ void to_lds16_lanes(const void* src, uint32_t dst) {
   if (WIDE_KO & 16) return;
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(src), "s"(dst)
-               : "memory");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst) : "memory");
+}
+
+// A 16-byte load into registers that the compiler does not count either (its own wait for the
+// value would be sized without the direct-to-LDS loads around it): the value may be used only
+// behind wait_loads, which names it.
+__device__ __forceinline__ void load16_uncounted(f32x4& dst, const float* src) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(src) : "memory");
+}
+template <int LEFT_IN_FLIGHT>
+__device__ __forceinline__ void wait_loads(f32x4& a, f32x4& b) {
+  // (a side build without the direct-to-LDS loads has nothing behind the register loads to count)
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"((WIDE_KO & 16) ? 0 : LEFT_IN_FLIGHT) : "memory");
 }
 
 __device__ __forceinline__ void pair_values(float x, float& lo, float& hi) {
@@ -157,8 +183,16 @@ __device__ __forceinline__ void scale_acc(f32x16& acc, float f) {
   asm volatile("" : "+a"(acc));
 }
 
+// Packed f32 arithmetic (v_pk_fma_f32, v_pk_mul_f32) issued beside matrix instructions stalls the SIMD
+// far longer than the two plain instructions it replaces; the kernel is compiled without it.
+#if defined(__HIP_DEVICE_COMPILE__) && !WIDE_PACKED
+#define MI355_NO_PACKED_F32 __attribute__((target("no-packed-fp32-ops")))
+#else
+#define MI355_NO_PACKED_F32
+#endif
+
 template <class Tag, int PAGED>
-__global__ void __launch_bounds__(256) mla_decode_kernel_wide(const MlaParams p) {
+__global__ void __launch_bounds__(256) MI355_NO_PACKED_F32 mla_decode_kernel_wide(const MlaParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_generic[];
   lds_byte_t* const lds = (lds_byte_t*)lds_generic;
 
@@ -204,7 +238,8 @@ __global__ void __launch_bounds__(256) mla_decode_kernel_wide(const MlaParams p)
     const int32_t* bt_row = p.bt + (int64_t)seq * p.max_blocks;
     const int b0 = t_begin >> p.bs_shift, b1 = (max(t_end, t_begin + 1) - 1) >> p.bs_shift;
     for (int b = b0 + tid; b <= b1; b += 256) ids[b - b0] = min(max(bt_row[min(b, p.max_blocks - 1)], 0), p.num_blocks - 1);
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the header's __syncthreads would stay out of line here)
+    __builtin_amdgcn_s_barrier();
   }
   const int blk0 = t_begin >> p.bs_shift;
 
@@ -214,24 +249,34 @@ __global__ void __launch_bounds__(256) mla_decode_kernel_wide(const MlaParams p)
   const int rr = 8 * wave + (lane >> 3);             // the rope row this lane fetches and rotates
   const int rslot = lane & 7, rswz = (rr >> 1) & 7;
   const uint32_t lds0 = (uint32_t)(uintptr_t)lds;   // LDS byte address of the image
-  // piece i of a tile's loads: 0 .. 7 the wave's c_kv rows, 8 its rope rows, 9 / 10 their cos / sin rows
-  auto issue_piece = [&](int i, int t0, int bufoff) __attribute__((always_inline)) {
+  // piece i of the direct-to-LDS loads of the tile at t0: 0 .. 7 the wave's c_kv rows (rows
+  // w, w + 4, ...), 8 its rope rows.  The byte offset of row w + 4i from the sequence's base is
+  // min(t0 + w, last) * stride + min(4i * stride, rows left behind it * stride): two scalar
+  // instructions per row once the two products are known (TileSrc, once per tile).
+  struct TileSrc {
+    uint32_t first, room;
+  };
+  const uint32_t lane16 = lane * 16;
+  auto tile_src = [&](int t0) __attribute__((always_inline)) {
+    const int last = t_end - 1, r0 = min(t0 + wave, last);
+    return TileSrc{(uint32_t)(r0 * cstride2), (uint32_t)((last - r0) * cstride2)};
+  };
+  auto issue_piece = [&](auto ic, int t0, const TileSrc& ts, int bufoff) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
     const int last = t_end - 1;
-    if (i < 8) {
-      const int r = wave + 4 * i;
-      const int tok = min(t0 + r, last);                 // wave-uniform
-      const char* src;
+    if constexpr (i < 8) {
+      const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + bufoff + wave * kPitch);
       if constexpr (is_paged(PAGED)) {
+        const int tok = min(t0 + wave + 4 * i, last);                 // wave-uniform
         const int id = *(const __attribute__((address_space(3))) int*)(lds + kIdsOff + 4 * ((tok >> p.bs_shift) - blk0));
-        src = ckv + ((int64_t)__builtin_amdgcn_readfirstlane(id) * p.ckv_stride_blk * 2 + (int64_t)(tok & p.bs_mask) * cstride2);
+        const char* src = ckv + ((int64_t)__builtin_amdgcn_readfirstlane(id) * p.ckv_stride_blk * 2 + (int64_t)(tok & p.bs_mask) * cstride2);
+        to_lds16_rows<row_off(4 * i)>(src, lane16, dst);
       } else {
-        src = ckv + (uint32_t)(tok * cstride2);
+        const uint32_t off = ts.first + min((uint32_t)(4 * i) * (uint32_t)cstride2, ts.room);
+        to_lds16_rows<row_off(4 * i)>(ckv, lane16 + off, dst);
       }
-      to_lds16_rows(src, lane * 16, __builtin_amdgcn_readfirstlane(lds0 + bufoff + row_off(r)));
-      return;
-    }
-    const int tokr = min(t0 + rr, last);
-    if (i == 8) {
+    } else {
+      const int tokr = min(t0 + rr, last);
       const char* rsrc;
       if constexpr (is_paged(PAGED)) {
         const int id = *(const __attribute__((address_space(3))) int*)(lds + kIdsOff + 4 * ((tokr >> p.bs_shift) - blk0));
@@ -240,184 +285,284 @@ __global__ void __launch_bounds__(256) mla_decode_kernel_wide(const MlaParams p)
         rsrc = krope + (uint32_t)(tokr * rstride2);
       }
       to_lds16_lanes(rsrc + ((rslot ^ rswz) << 4), __builtin_amdgcn_readfirstlane(lds0 + bufoff + kRopeOff + wave * 1024));
-      return;
     }
-    const int pos = min(tokr, p.table_len - 1);
-    if (i == 9) to_lds16_lanes(p.cos_t + (int64_t)pos * kP + 4 * rslot, __builtin_amdgcn_readfirstlane(lds0 + bufoff + kCosOff + wave * 1024));
-    else to_lds16_lanes(p.sin_t + (int64_t)pos * kP + 4 * rslot, __builtin_amdgcn_readfirstlane(lds0 + bufoff + kSinOff + wave * 1024));
   };
-  auto issue_tile = [&](int t0, int bufoff) {
-#pragma unroll
-    for (int i = 0; i < kLoadsPerTile; ++i) issue_piece(i, t0, bufoff);
+  auto issue_tile = [&](int t0, int bufoff) __attribute__((always_inline)) {
+    const TileSrc ts = tile_src(t0);
+    static_for<0, kLdsLoads>([&](auto ic) __attribute__((always_inline)) { issue_piece(ic, t0, ts, bufoff); });
+  };
+  // cos / sin columns 4 rslot .. + 4 of the position of rope row rr of the tile at t0, into registers
+  f32x4 cv, sv;
+  auto issue_factor = [&](auto which, int t0) __attribute__((always_inline)) {
+    const int pos = min(min(t0 + rr, t_end - 1), p.table_len - 1);
+    if constexpr (decltype(which)::value == 0) load16_uncounted(cv, p.cos_t + (int64_t)pos * kP + 4 * rslot);
+    else load16_uncounted(sv, p.sin_t + (int64_t)pos * kP + 4 * rslot);
+  };
+  auto issue_factors = [&](int t0) __attribute__((always_inline)) {
+    issue_factor(std::integral_constant<int, 0>{}, t0);
+    issue_factor(std::integral_constant<int, 1>{}, t0);
   };
 
   // Rotation of this lane's four (lo, hi) pairs of rope row rr: dims 4 rslot .. + 4 and their
-  // partners 32 dims on, with cos / sin columns 4 rslot .. + 4 of the row's position.
-  auto rotate = [&](int bufoff) {
+  // partners 32 dims on, by the factors in cv / sv.  In pieces (0: read, 1 / 2: unpack, 3 .. 6: one
+  // pair each, 7 / 8: pack, 9: write), so that they can be dealt out between matrix instructions.
+  constexpr int kRotatePieces = 10;
+  u32x2 rot_lo2, rot_hi2;
+  float rot_lo[4], rot_hi[4], rot_nlo[4], rot_nhi[4];
+  auto rotate_piece = [&](auto kc, int bufoff) __attribute__((always_inline)) {
+    constexpr int k = decltype(kc)::value;
+    if constexpr ((WIDE_KO & 64) != 0) return;
     lds_byte_t* lo_p = lds + bufoff + kRopeOff + rr * 128 + (((rslot >> 1) ^ rswz) << 4) + (rslot & 1) * 8;
     lds_byte_t* hi_p = lds + bufoff + kRopeOff + rr * 128 + (((4 + (rslot >> 1)) ^ rswz) << 4) + (rslot & 1) * 8;
-    const f32x4 cv = *(const __attribute__((address_space(3))) f32x4*)(lds + bufoff + kCosOff + rr * 128 + rslot * 16);
-    const f32x4 sv = *(const __attribute__((address_space(3))) f32x4*)(lds + bufoff + kSinOff + rr * 128 + rslot * 16);
-    const u32x2 lo2 = *(const __attribute__((address_space(3))) u32x2*)lo_p;
-    const u32x2 hi2 = *(const __attribute__((address_space(3))) u32x2*)hi_p;
-    float lo[4], hi[4], nlo[4], nhi[4];
+    if constexpr (k == 0) {
+      rot_lo2 = *(const __attribute__((address_space(3))) u32x2*)lo_p;
+      rot_hi2 = *(const __attribute__((address_space(3))) u32x2*)hi_p;
+    } else if constexpr (k == 1) {
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      lo[2 * k] = Tag::to_float((typename Tag::elem_t)(lo2[k] & 0xffffu));
-      lo[2 * k + 1] = Tag::to_float((typename Tag::elem_t)(lo2[k] >> 16));
-      hi[2 * k] = Tag::to_float((typename Tag::elem_t)(hi2[k] & 0xffffu));
-      hi[2 * k + 1] = Tag::to_float((typename Tag::elem_t)(hi2[k] >> 16));
-    }
+      for (int j = 0; j < 2; ++j) {
+        rot_lo[2 * j] = Tag::to_float((typename Tag::elem_t)(rot_lo2[j] & 0xffffu));
+        rot_lo[2 * j + 1] = Tag::to_float((typename Tag::elem_t)(rot_lo2[j] >> 16));
+      }
+    } else if constexpr (k == 2) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      nlo[k] = lo[k] * cv[k] - hi[k] * sv[k];
-      nhi[k] = hi[k] * cv[k] + lo[k] * sv[k];
+      for (int j = 0; j < 2; ++j) {
+        rot_hi[2 * j] = Tag::to_float((typename Tag::elem_t)(rot_hi2[j] & 0xffffu));
+        rot_hi[2 * j + 1] = Tag::to_float((typename Tag::elem_t)(rot_hi2[j] >> 16));
+      }
+    } else if constexpr (k < 7) {
+      constexpr int j = k - 3;
+      rot_nlo[j] = rot_lo[j] * cv[j] - rot_hi[j] * sv[j];
+      rot_nhi[j] = rot_hi[j] * cv[j] + rot_lo[j] * sv[j];
+    } else if constexpr (k == 7) {
+      rot_lo2 = u32x2{Mma32<Tag>::pack2(rot_nlo[0], rot_nlo[1]), Mma32<Tag>::pack2(rot_nlo[2], rot_nlo[3])};
+    } else if constexpr (k == 8) {
+      rot_hi2 = u32x2{Mma32<Tag>::pack2(rot_nhi[0], rot_nhi[1]), Mma32<Tag>::pack2(rot_nhi[2], rot_nhi[3])};
+    } else {
+      *(__attribute__((address_space(3))) u32x2*)lo_p = rot_lo2;
+      *(__attribute__((address_space(3))) u32x2*)hi_p = rot_hi2;
     }
-    *(__attribute__((address_space(3))) u32x2*)lo_p = u32x2{Mma32<Tag>::pack2(nlo[0], nlo[1]), Mma32<Tag>::pack2(nlo[2], nlo[3])};
-    *(__attribute__((address_space(3))) u32x2*)hi_p = u32x2{Mma32<Tag>::pack2(nhi[0], nhi[1]), Mma32<Tag>::pack2(nhi[2], nhi[3])};
+  };
+  auto rotate = [&](int bufoff) __attribute__((always_inline)) {
+    static_for<0, kRotatePieces>([&](auto kc) __attribute__((always_inline)) { rotate_piece(kc, bufoff); });
   };
 
+#if WIDE_TIMING
+  // side build: shader-clock time of wave 0 of workgroup 0 spent up to the barrier's release, in
+  // the score phase and in the value phase of its steps (written over the head of the output)
+  unsigned long long tm_prev = 0, tm_bar = 0, tm_s = 0, tm_pv = 0;
+#define WIDE_STAMP(acc)                                              \
+  {                                                                  \
+    const unsigned long long now = __builtin_readcyclecounter();     \
+    acc += now - tm_prev;                                            \
+    tm_prev = now;                                                   \
+  }
+#else
+#define WIDE_STAMP(acc)
+#endif
   // Per-lane LDS offsets of the operands (buffer offset added per tile).
   const int k_lane = row_off(c) + h * 16;                                  // K operand, latent k-steps: + 32 ks
   const int kr_lane = kRopeOff + c * 128, kr_swz = (c >> 1) & 7;           // rope k-steps: chunk (2 (ks - 32) + h) ^ swz
   const int grp = (lane >> 4) & 1, qi = (lane & 15) >> 2, pi = lane & 3;
   const int v_lane = (4 * h + qi) * kPitch + h * 16 + (16 * grp + 4 * pi) * 2;   // V^T operand
+  const float scale = p.scale_log2e;                                       // > 0 (checked by the host)
 
-  // One tile of a live wave, in the order the instructions should issue (the asm statements keep
-  // their order): the score product with the loads of tile t + 2 dealt out between its matrix
-  // instructions; maximum and the first half of the weights; the first half of the value product
-  // with the second half of the weights in its shadow; the second half of the value product with,
-  // in its shadow, the wait for this wave's loads of tile t + 1 and the rotation of their rope rows.
-  auto tile_step = [&](int t0, int bufoff, int next_t0, int next2_t0, int bufoff_next, int bufoff_next2) {
-    // ---- S^T = K . Q^T
-    f32x16 st;
-    {
-      constexpr int kAhead = WIDE_KA;
-      auto a_at = [&](int n) __attribute__((always_inline)) {
-        if (WIDE_KO & 2) return u32x4{(uint32_t)lane, 0u, 0u, 0u};
-        if (n < kR / 16) return *(const __attribute__((address_space(3))) u32x4*)(lds + bufoff + k_lane + 32 * n);
-        return *(const __attribute__((address_space(3))) u32x4*)(lds + bufoff + kr_lane + (((2 * (n - kR / 16) + h) ^ kr_swz) << 4));
-      };
-      u32x4 abuf[kAhead];
+  // S^T = K . Q^T of the tile in buffer `bufoff` into st; `between(n)` is issued after the n-th
+  // matrix instruction.
+  auto score_product = [&](f32x16& st, int bufoff, auto final_wait, auto between) __attribute__((always_inline)) {
+    auto a_at = [&](int n) __attribute__((always_inline)) {
+      if (WIDE_KO & 2) return u32x4{(uint32_t)lane, 0u, 0u, 0u};
+      if (n < kR / 16) return *(const __attribute__((address_space(3))) u32x4*)(lds + bufoff + k_lane + 32 * n);
+      return *(const __attribute__((address_space(3))) u32x4*)(lds + bufoff + kr_lane + (((2 * (n - kR / 16) + h) ^ kr_swz) << 4));
+    };
+    // Operands are read in groups of kGroup, two groups ahead: the wait ahead of a group's first
+    // matrix instruction then covers the whole group (one s_waitcnt per kGroup matrix
+    // instructions instead of one each; at one wave per SIMD every instruction issued counts).
+    constexpr int kGroup = WIDE_KG, kGroups = kKS / kGroup, kAhead = 2 * kGroup;
+    static_assert(kKS % kGroup == 0, "operand groups");
+    u32x4 abuf[kAhead];
 #pragma unroll
-      for (int n = 0; n < kAhead; ++n) abuf[n] = a_at(n);
-#pragma unroll
-      for (int n = 0; n < kKS; ++n) {
+    for (int n = 0; n < kAhead; ++n) abuf[n] = a_at(n);
+    static_for<0, kGroups>([&](auto gc) __attribute__((always_inline)) {
+      constexpr int g = decltype(gc)::value;
+      static_for<0, kGroup>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int n = g * kGroup + decltype(jc)::value;
         const u32x4 a = abuf[n % kAhead];
-        if (n + kAhead < kKS) abuf[n % kAhead] = a_at(n + kAhead);
-        if (WIDE_KO & 1) {
-          if (n == 0) st = f32x16(0.f);
+        if constexpr ((WIDE_KO & 1) != 0) {
+          if constexpr (n == 0) st = f32x16(0.f);
           asm volatile("" ::"v"(a));
-        } else if (n == 0) score_mma<Tag, true, false>(st, a, qf[n]);
-        else if (n == kKS - 1) score_mma<Tag, false, true>(st, a, qf[n]);
+        } else if constexpr (n == 0) score_mma<Tag, true, false>(st, a, qf[n]);
+        else if constexpr (n == kKS - 1) score_mma<Tag, false, decltype(final_wait)::value>(st, a, qf[n]);
         else score_mma<Tag, false, false>(st, a, qf[n]);
-        if (n % 3 == 1 && n / 3 < kLoadsPerTile) issue_piece(n / 3, next2_t0, bufoff_next2);
+        between(std::integral_constant<int, n>{});
+      });
+      if constexpr (g + 2 < kGroups) {
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j) abuf[(g * kGroup + j) % kAhead] = a_at((g + 2) * kGroup + j);
       }
-    }
-    // ---- online softmax; register i of lane (c, h) is token t0 + 8 (i / 4) + 4 h + i % 4 of head c
-    float mx = -__builtin_inff();
-    if (t0 + kTile > t_end) {
+    });
+  };
+
+  // One step of a live wave: the score product of tile t + 1 (into st_next) with the softmax
+  // arithmetic of tile t (from st_cur) and the loads of tile t + 3 between its matrix instructions,
+  // then the value product of tile t with the wait for and rotation of tile t + 2 in its shadow.
+  // b0 .. b3: the buffers of tiles t .. t + 3.
+  auto tile_step = [&](int t0, f32x16& st_cur, f32x16& st_next, int b0, int b1, int b2, int b3) __attribute__((always_inline)) {
+    // What goes where.  A matrix instruction occupies the pipe for 32 cycles; measured with one
+    // wave per SIMD (tools/micro/mfma_valu_coissue.hip), about five plain VALU instructions, or two
+    // to three exponentials, issued behind it are free, and whatever exceeds that in ONE slot delays
+    // the next matrix instruction -- slack in a later slot does not pay it back.  So every slot of
+    // the score product gets one LDS operand read and at most an exponential with its multiply-add
+    // and its addition, or four plain instructions, or one load with its address arithmetic.
+    float mxa, mxb, mxc, mxd, ps = 0.f;
+    u32x4 pb[2];
+    auto softmax_piece = [&](auto kc) __attribute__((always_inline)) {
+      constexpr int k = decltype(kc)::value;   // 0 .. 3 maximum, 4 .. 19 weights, 20 / 21 packing, 22 sum
+      if constexpr ((WIDE_KO & 32) != 0) {   // no softmax arithmetic: the weights are the raw scores' bits
+        if constexpr (k == 20 || k == 21) {
+          constexpr int u = k - 20;
 #pragma unroll
-      for (int i = 0; i < 16; ++i)
-        st[i] = (t0 + 8 * (i >> 2) + 4 * h + (i & 3) < t_end) ? st[i] * p.scale_log2e : -__builtin_inff();
-    } else {
-      st = st * p.scale_log2e;
-    }
+          for (int w = 0; w < 4; ++w) pb[u][w] = f2u(st_cur[8 * u + 2 * w]);
+        }
+        return;
+      }
+      // register i of lane (c, h) is token t0 + 8 (i / 4) + 4 h + i % 4 of head c
+      if constexpr (k == 0) {
+        if (t0 + kTile > t_end) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, st[i]);
-    {
-      float a, b;
-      pair_values(mx, a, b);
-      mx = fmaxf(a, b);
-    }
-    // Deferred rescale (as in the 16-heads-per-wave kernel): the reference m_run moves only when
-    // some head's maximum outgrows it by 2^8, so the 256 accumulator registers are rescaled on a
-    // handful of tiles per sequence; sums, outputs and split records are relative to the same m_run.
-    constexpr float kDefer = 8.f;
-    if (__builtin_amdgcn_ballot_w64(mx > m_run + kDefer) != 0) {
-      const float m_new = fmaxf(m_run, mx);
-      const float f = fast_exp2(m_run - m_new);
-      m_run = m_new;
-      l_run *= f;
+          for (int i = 0; i < 16; ++i)
+            if (t0 + 8 * (i >> 2) + 4 * h + (i & 3) >= t_end) st_cur[i] = -__builtin_inff();
+        }
+        mxa = __builtin_fmaxf(__builtin_fmaxf(st_cur[0], st_cur[1]), st_cur[2]);
+        mxb = __builtin_fmaxf(__builtin_fmaxf(st_cur[3], st_cur[4]), st_cur[5]);
+      } else if constexpr (k == 1) {
+        mxc = __builtin_fmaxf(__builtin_fmaxf(st_cur[6], st_cur[7]), st_cur[8]);
+        mxd = __builtin_fmaxf(__builtin_fmaxf(st_cur[9], st_cur[10]), st_cur[11]);
+      } else if constexpr (k == 2) {
+        mxa = __builtin_fmaxf(__builtin_fmaxf(mxa, mxb), mxc);
+        mxb = __builtin_fmaxf(__builtin_fmaxf(st_cur[12], st_cur[13]), st_cur[14]);
+        mxa = __builtin_fmaxf(__builtin_fmaxf(mxa, mxb), mxd);
+        mxa = __builtin_fmaxf(mxa, st_cur[15]);
+      } else if constexpr (k == 3) {
+        float a, b;
+        pair_values(mxa, a, b);
+        const float mx = __builtin_fmaxf(a, b) * scale;
+        // Deferred rescale (as in the 16-heads-per-wave kernel): the reference m_run moves only when
+        // some head's maximum outgrows it by 2^8, so the 256 accumulator registers are rescaled on a
+        // handful of tiles per sequence; sums, outputs and split records are relative to the same
+        // m_run.  (The value product that last wrote the accumulators has left the matrix pipe: the
+        // score product's instructions issued since then went in behind it.)
+        constexpr float kDefer = 8.f;
+        if (__builtin_amdgcn_ballot_w64(mx > m_run + kDefer) != 0) {
+          const float m_new = fmaxf(m_run, mx);
+          const float f = fast_exp2(m_run - m_new);
+          m_run = m_new;
+          l_run *= f;
 #pragma unroll
-      for (int i = 0; i < kDB; ++i) scale_acc(o[i], f);
-    }
-    // ---- O^T += V^T . P^T.  k-slot j of lane half h in step u is token 16 u + 8 (j / 4) + 4 h + j % 4:
-    // registers 8 u .. 8 u + 7 of P as they stand, two transposing 4-token reads of V.
-    constexpr int NV = 2 * kDB, kAheadV = WIDE_KAV;
+          for (int i = 0; i < kDB; ++i) scale_acc(o[i], f);
+        }
+      } else if constexpr (k < 20) {
+        constexpr int i = k - 4;
+        st_cur[i] = fast_exp2(__builtin_fmaf(st_cur[i], scale, -m_run));
+        ps += st_cur[i];
+      } else if constexpr (k < 22) {           // k-slot j of lane half h in step u is token 16 u + 8 (j / 4) + 4 h + j % 4:
+        constexpr int u = k - 20;              // registers 8 u .. 8 u + 7 of the weights as they stand
+#pragma unroll
+        for (int w = 0; w < 4; ++w) pb[u][w] = Mma32<Tag>::pack2(st_cur[8 * u + 2 * w], st_cur[8 * u + 2 * w + 1]);
+      } else {
+        l_run += ps;
+      }
+    };
+    const TileSrc ts3 = tile_src(t0 + 3 * kTile);
+    score_product(st_next, b1, std::false_type{}, [&](auto nc) __attribute__((always_inline)) {
+      constexpr int n = decltype(nc)::value;
+      if constexpr (n < 2) issue_factor(nc, t0 + 2 * kTile);                                  // (ahead of this step's direct-to-LDS loads)
+      else if constexpr (n < 25) softmax_piece(std::integral_constant<int, n - 2>{});
+      else if constexpr (n < 25 + kLdsLoads) issue_piece(std::integral_constant<int, n - 25>{}, t0 + 3 * kTile, ts3, b3);
+    });
+    WIDE_STAMP(tm_s)
+    // ---- O^T += V^T . P^T of tile t
+    constexpr int NV = 2 * kDB;
     auto v_at = [&](int n) __attribute__((always_inline)) {   // n-th operand: step u = n / kDB, dim block n % kDB
       if (WIDE_KO & 8) return u32x4{(uint32_t)lane, 0u, 0u, 0u};
-      const int off = bufoff + v_lane + (16 * (n / kDB)) * kPitch + (n % kDB) * 64;
+      const int off = b0 + v_lane + (16 * (n / kDB)) * kPitch + (n % kDB) * 64;
       const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + off));
       const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
           (__attribute__((address_space(3))) s16x4*)(lds + off + 8 * kPitch + 32));
       const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
       return u32x4{lo2[0], lo2[1], hi2[0], hi2[1]};
     };
+    constexpr int kGroupV = WIDE_KGV, kGroupsV = NV / kGroupV, kAheadV = 2 * kGroupV;
+    static_assert(NV % kGroupV == 0, "operand groups");
     u32x4 vbuf[kAheadV];
 #pragma unroll
     for (int n = 0; n < kAheadV; ++n) vbuf[n] = v_at(n);
-    float ps = 0.f;
-    u32x4 pb[2];
+    static_for<0, kGroupsV>([&](auto gc) __attribute__((always_inline)) {
+      constexpr int g = decltype(gc)::value;
+      static_for<0, kGroupV>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int n = g * kGroupV + decltype(jc)::value;
+        const u32x4 va = vbuf[n % kAheadV];
+        out_mma<Tag>(o[n % kDB], va, pb[n / kDB]);
+        if constexpr (n + 2 * kGroupV < NV && kGroupV == 1) vbuf[n % kAheadV] = v_at(n + kAheadV);
+        // the rope rows of tile t + 2: this wave's part of the tile and its factors are in once only
+        // tile t + 3's loads are left in flight
+        if constexpr (n == 6) wait_loads<kLdsLoads>(cv, sv);
+        if constexpr (n >= 6 && n < 6 + 2 * kRotatePieces && n % 2 == 0) rotate_piece(std::integral_constant<int, (n - 6) / 2>{}, b2);
+      });
+      if constexpr (g + 2 < kGroupsV && kGroupV > 1) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      st[i] = fast_exp2(st[i] - m_run);
-      ps += st[i];
-    }
-#pragma unroll
-    for (int w = 0; w < 4; ++w) pb[0][w] = Mma32<Tag>::pack2(st[2 * w], st[2 * w + 1]);
-    asm volatile("s_nop 3");   // the packed weights come straight from the VALU; the compiler does not see their consumer
-#pragma unroll
-    for (int n = 0; n < NV; ++n) {
-      const u32x4 va = vbuf[n % kAheadV];
-      if (n + kAheadV < NV) vbuf[n % kAheadV] = v_at(n + kAheadV);
-      if (WIDE_KO & 4) asm volatile("" ::"v"(va), "v"(pb[n / kDB]));
-      else out_mma<Tag>(o[n % kDB], va, pb[n / kDB]);
-      if (n < 8) {   // the second half of the weights, two per matrix instruction of the first half
-        st[8 + n] = fast_exp2(st[8 + n] - m_run);
-        ps += st[8 + n];
+        for (int j = 0; j < kGroupV; ++j) vbuf[(g * kGroupV + j) % kAheadV] = v_at((g + 2) * kGroupV + j);
       }
-      if (n == 9) {
-#pragma unroll
-        for (int w = 0; w < 4; ++w) pb[1][w] = Mma32<Tag>::pack2(st[8 + 2 * w], st[8 + 2 * w + 1]);
-        l_run += ps;
-      }
-      if (n == kDB - 1) asm volatile("s_nop 1");
-      if (n == kDB + 1) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLoadsPerTile) : "memory");
-        rotate(bufoff_next);
-      }
-    }
-    (void)next_t0;
+    });
   };
 
-  // Tile t lives in buffer t mod 3.  A tile's loads go out two tiles ahead (during tile t - 2's
-  // score product), are waited for by the wave that issued them one tile ahead (which then rotates
-  // the rope rows among them), and the barrier at the top of tile t makes everybody's part visible
-  // to everybody -- and says that everybody is done reading tile t - 1, whose buffer the loads of
-  // tile t + 2 then overwrite.  Loads past the last tile are issued all the same (clamped to the
-  // last row), so that the count of loads in flight is the same at every wait.
+  // Tile t lives in buffer t mod 4.  Its loads go out during step t - 3, are waited for by the wave
+  // that issued them during step t - 2 (which then rotates the rope rows among them), and the
+  // barrier at the top of step t - 1 makes everybody's part visible to everybody before the score
+  // product of tile t runs in that step -- and says that everybody is done with tile t - 2, whose
+  // buffer the loads of tile t + 2 then overwrite.  Loads past the last tile are issued all the same
+  // (clamped to the last row), so that the count of loads in flight is the same at every wait; the
+  // score product of the tile past the last is computed and dropped.
   if (ntiles > 0) {
+    f32x16 st_a, st_b;
     issue_tile(t_begin, 0);
+    issue_factors(t_begin);
     issue_tile(t_begin + kTile, kBufBytes);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLoadsPerTile) : "memory");
+    issue_tile(t_begin + 2 * kTile, 2 * kBufBytes);
+    wait_loads<2 * kLdsLoads>(cv, sv);
     rotate(0);
-    int cur = 0, nxt = kBufBytes, nxt2 = 2 * kBufBytes;
-    for (int t = 0; t < ntiles; ++t) {
+    issue_factors(t_begin + kTile);
+    wait_loads<0>(cv, sv);
+    rotate(kBufBytes);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wave_live) score_product(st_a, 0, std::true_type{}, [](auto) __attribute__((always_inline)) {});
+    int b0 = 0, b1 = kBufBytes, b2 = 2 * kBufBytes, b3 = 3 * kBufBytes;
+#if WIDE_TIMING
+    tm_prev = __builtin_readcyclecounter();
+#endif
+    auto step = [&](int t, f32x16& st_cur, f32x16& st_next) __attribute__((always_inline)) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      WIDE_STAMP(tm_bar)
       const int t0 = t_begin + t * kTile;
       if (wave_live) {
-        tile_step(t0, cur, t0 + kTile, t0 + 2 * kTile, nxt, nxt2);
+        tile_step(t0, st_cur, st_next, b0, b1, b2, b3);
       } else {   // a wave without heads only stages
-        issue_tile(t0 + 2 * kTile, nxt2);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLoadsPerTile) : "memory");
-        rotate(nxt);
+        issue_factors(t0 + 2 * kTile);
+        issue_tile(t0 + 3 * kTile, b3);
+        wait_loads<kLdsLoads>(cv, sv);
+        rotate(b2);
       }
-      const int c0 = cur;
-      cur = nxt;
-      nxt = nxt2;
-      nxt2 = c0;
+      WIDE_STAMP(tm_pv)
+      const int f = b0;
+      b0 = b1;
+      b1 = b2;
+      b2 = b3;
+      b3 = f;
+    };
+    for (int t = 0; t < ntiles; t += 2) {
+      step(t, st_a, st_b);
+      if (t + 1 < ntiles) step(t + 1, st_b, st_a);
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 3" ::: "memory");   // (+ the last matrix results are readable)
   }
@@ -451,6 +596,16 @@ __global__ void __launch_bounds__(256) mla_decode_kernel_wide(const MlaParams p)
       const f32x4 v = {o[db][4 * g4], o[db][4 * g4 + 1], o[db][4 * g4 + 2], o[db][4 * g4 + 3]};
       *reinterpret_cast<f32x4*>(dst + 32 * db + 8 * g4) = v * inv;
     }
+#if WIDE_TIMING
+  if (blockIdx.x == 0 && tid == 0) {
+    __builtin_amdgcn_s_waitcnt(0);
+    unsigned long long* t = reinterpret_cast<unsigned long long*>(p.out);
+    t[0] = tm_bar;
+    t[1] = tm_s;
+    t[2] = tm_pv;
+    t[3] = (unsigned long long)ntiles;
+  }
+#endif
 }
 
 template <class Tag, int PAGED>
