@@ -40,7 +40,7 @@ enum Knob {
   kKnobPagedBalanceWgs,   // MI355_PAGED_BALANCE_WGS   workgroups a decode launch spreads its kv heads over for ragged batches (0: off)
   kKnobDpExchangeProbe,   // MI355_DP_EXCHANGE_PROBE   measurement only, bit mask: 1 no collective, 2 no completion event, 4 no watcher
   kKnobMlaRowGroups,      // MI355_MLA_ROW_GROUPS      1: paged rank-512 MLA tiles staged as 8 consecutive rows per wave
-  kKnobMlaWide,           // MI355_MLA_WIDE            1: 128 heads per MLA workgroup above 64 heads (rank 512, rope 64)
+  kKnobMlaWide,           // MI355_MLA_WIDE            fewest heads served by the 128-heads-per-workgroup MLA kernel (rank 512, rope 64); 0: off
   kKnobCount
 };
 int knob(Knob k);

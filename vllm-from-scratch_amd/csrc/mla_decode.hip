@@ -881,7 +881,7 @@ int mla_plan(int rows, int H, int R, int P, int max_context, int dtype, MlaPlan*
   if (max_context < 0) return fail(MI355_EINVAL, "mla_decode: max_context %d", max_context);
   MlaPlan pl;
   pl.many = R >= 128 && H > kHeadTile && knob(kKnobMlaManyHeads) != 0;   // 64 heads per workgroup
-  pl.wide = pl.many && mla_wide_supported(H, R, P, dtype) && knob(kKnobMlaWide) != 0;
+  pl.wide = pl.many && mla_wide_supported(H, R, P, dtype);
   pl.n_ht = pl.wide ? (H + 127) / 128 : pl.many ? (H + 4 * kHeadTile - 1) / (4 * kHeadTile) : (H + kHeadTile - 1) / kHeadTile;
   const int ctx = max_context > 0 ? max_context : 1;
   const int64_t base = (int64_t)rows * pl.n_ht;

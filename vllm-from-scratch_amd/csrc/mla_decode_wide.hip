@@ -628,7 +628,8 @@ int launch_wide(const MlaParams& p, hipStream_t s) {
 }  // namespace
 
 bool mla_wide_supported(int H, int R, int P, int dtype) {
-  return R == kR && P == kP && H > 64 && (dtype == MI355_BF16 || dtype == MI355_F16);
+  const int least = knob(kKnobMlaWide);   // 0: off
+  return least > 0 && R == kR && P == kP && H >= least && (dtype == MI355_BF16 || dtype == MI355_F16);
 }
 
 // Most tokens per workgroup a paged launch can hold block ids for (the plan splits longer ranges).
