@@ -1,5 +1,7 @@
-// Latent-space MLA attention for many heads: 128 heads per workgroup on v_mfma_f32_32x32x16.
+// Latent-space MLA attention for more than 16 heads: 128 heads per workgroup on v_mfma_f32_32x32x16.
 //
+// Replaces the attention core of the reference's MLA module (04_mla/mini_mla.py:234-299) for
+// kv_lora_rank 512 and a rope slot of 64, like the other kernels of mla_decode.hip.
 // With the up-projections absorbed (see mla_decode.hip) every cached row [c_kv | rope(k_rope)] of
 // kv_lora_rank + rope = 512 + 64 dims serves all H heads.  At 128 heads the work per cached byte is
 // ~220 flop, so the kernel is bound by the matrix pipe and by what feeds it: the 16-heads-per-wave
