@@ -474,15 +474,6 @@ __global__ void __launch_bounds__(256) MI355_NO_PACKED_F32 mla_decode_kernel_wid
         l_run += ps;
       }
     };
-    const TileSrc ts3 = tile_src(t0 + 3 * kTile);
-    score_product(st_next, b1, std::false_type{}, [&](auto nc) __attribute__((always_inline)) {
-      constexpr int n = decltype(nc)::value;
-      if constexpr (n < 2) issue_factor(nc, t0 + 2 * kTile);                                  // (ahead of this step's direct-to-LDS loads)
-      else if constexpr (n < 25) softmax_piece(std::integral_constant<int, n - 2>{});
-      else if constexpr (n < 25 + kLdsLoads) issue_piece(std::integral_constant<int, n - 25>{}, t0 + 3 * kTile, ts3, b3);
-    });
-    WIDE_STAMP(tm_s)
-    // ---- O^T += V^T . P^T of tile t
     constexpr int NV = 2 * kDB;
     auto v_at = [&](int n) __attribute__((always_inline)) {   // n-th operand: step u = n / kDB, dim block n % kDB
       if (WIDE_KO & 8) return u32x4{(uint32_t)lane, 0u, 0u, 0u};
@@ -496,8 +487,19 @@ __global__ void __launch_bounds__(256) MI355_NO_PACKED_F32 mla_decode_kernel_wid
     constexpr int kGroupV = WIDE_KGV, kGroupsV = NV / kGroupV, kAheadV = 2 * kGroupV;
     static_assert(NV % kGroupV == 0, "operand groups");
     u32x4 vbuf[kAheadV];
+    const TileSrc ts3 = tile_src(t0 + 3 * kTile);
+    score_product(st_next, b1, std::false_type{}, [&](auto nc) __attribute__((always_inline)) {
+      constexpr int n = decltype(nc)::value;
+      if constexpr (n < 2) issue_factor(nc, t0 + 2 * kTile);                                  // (ahead of this step's direct-to-LDS loads)
+      else if constexpr (n < 25) softmax_piece(std::integral_constant<int, n - 2>{});
+      else if constexpr (n < 25 + kLdsLoads) issue_piece(std::integral_constant<int, n - 25>{}, t0 + 3 * kTile, ts3, b3);
+      else if constexpr (n == 25 + kLdsLoads) {   // the value product's first operands: their LDS round trip passes here
 #pragma unroll
-    for (int n = 0; n < kAheadV; ++n) vbuf[n] = v_at(n);
+        for (int j = 0; j < kAheadV; ++j) vbuf[j] = v_at(j);
+      }
+    });
+    WIDE_STAMP(tm_s)
+    // ---- O^T += V^T . P^T of tile t
     static_for<0, kGroupsV>([&](auto gc) __attribute__((always_inline)) {
       constexpr int g = decltype(gc)::value;
       static_for<0, kGroupV>([&](auto jc) __attribute__((always_inline)) {
