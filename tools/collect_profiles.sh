@@ -22,6 +22,8 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/
   python3 tools/bench_gqa.py > "$OUT/gqa_under_rocprof.txt" 2> "$OUT/trace_gqa.log"
 MLA_TARGETS=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_mla" -o mla -- \
   python3 tools/bench_mla.py 256 16 4096 > "$OUT/mla_under_rocprof.txt" 2> "$OUT/trace_mla.log"
+MLA_TARGETS=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_mla_wide" -o mla_wide -- \
+  python3 tools/bench_mla.py 128 128 4096 > "$OUT/mla_wide_under_rocprof.txt" 2> "$OUT/trace_mla_wide.log"
 BENCH_MFMA_ONLY=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_prefill" -o prefill -- \
   python3 tools/bench_prefill.py 4 8192 32 8 128 > "$OUT/prefill_under_rocprof.txt" 2> "$OUT/trace_prefill.log"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_paged_prefill" -o pp -- \
@@ -38,6 +40,10 @@ step "kernel trace of the one-rank rehearsal of the multi-rank step, exchange st
 MASTER_ADDR=127.0.0.1 MASTER_PORT=29519 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 BENCH_FORCE_DIST=1 \
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_exchange" -o exchange -- \
   python3 bench.py --no-cpu-baseline --steps 100 > "$OUT/bench_line_exchange_under_rocprof.json" 2> "$OUT/trace_exchange.log"
+if [ -f tools/_ab/lib_wide_timing.so ]; then
+  step phases of a step of the 128-heads-per-workgroup MLA kernel from the stamped side build
+  MI355_PAGED_LIB=$PWD/tools/_ab/lib_wide_timing.so timeout -k 10 200 python3 tools/probe_wide_timeline.py > "$OUT/mla_wide_phases.txt" 2> "$OUT/mla_wide_phases.err"
+fi
 if [ -f tools/_ab/lib_samp_t.so ]; then
   step sampler phases from the stamped side build
   MI355_PAGED_LIB=tools/_ab/lib_samp_t.so timeout -k 10 200 python3 tools/probe_sampler_phases.py > "$OUT/sampler_phases.txt" 2> "$OUT/sampler_phases.err"
@@ -48,7 +54,8 @@ export MI355_WARM_SECONDS=0.05 MLA_WARM_SECONDS=0.05   # (counter passes seriali
 BENCH_MFMA_ONLY=1 tools/pmc_sq.sh "$OUT/pmc_prefill_d128" prefill_mfma tools/bench_prefill.py 4 8192 32 8 128 > "$OUT/pmc_prefill_d128.txt"
 BENCH_MFMA_ONLY=1 tools/pmc_sq.sh "$OUT/pmc_prefill_d64" prefill_mfma tools/bench_prefill.py 2 16384 8 8 64 > "$OUT/pmc_prefill_d64.txt"
 tools/pmc_sq.sh "$OUT/pmc_prefill_f32" prefill_mfma_f32 tools/bench_prefill_fp32.py 16 2048 8 8 64 > "$OUT/pmc_prefill_f32.txt"
-MLA_TARGETS=0 tools/pmc_sq.sh "$OUT/pmc_mla_mh" mla_decode_kernel_mh tools/bench_mla.py 128 128 4096 > "$OUT/pmc_mla_mh.txt"
+MLA_TARGETS=0 tools/pmc_sq.sh "$OUT/pmc_mla_wide" mla_decode_kernel_wide tools/bench_mla.py 256 128 4096 > "$OUT/pmc_mla_wide.txt"
+MI355_MLA_WIDE=0 MLA_TARGETS=0 tools/pmc_sq.sh "$OUT/pmc_mla_mh" mla_decode_kernel_mh tools/bench_mla.py 128 128 4096 > "$OUT/pmc_mla_mh.txt"
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_mla_fetch" -o fetch -- \
   python3 tools/bench_mla.py 256 16 4096 > /dev/null 2> "$OUT/pmc_mla_fetch.log"
 
@@ -69,7 +76,9 @@ if [ "$PART" != secondary2 ]; then
   timeout -k 10 200 python3 tools/tune_c2.py metric
   timeout -k 10 200 python3 tools/bench_argmax.py
   timeout -k 10 200 python3 tools/bench_argmax.py 256 1000
-  for a in "64 16 4096" "256 16 4096" "128 16 8192" "64 32 4096" "32 64 4096" "128 128 4096"; do MLA_TARGETS=0,0 timeout -k 10 120 python3 tools/bench_mla.py $a | tail -1; done
+  for a in "64 16 4096" "256 16 4096" "128 16 8192" "64 32 4096" "32 64 4096" "128 128 4096" "256 128 4096" "256 64 4096" "256 32 4096" "64 128 8192"; do MLA_TARGETS=0,0 timeout -k 10 120 python3 tools/bench_mla.py $a | tail -1; done
+  echo "more than 16 heads on the 64-heads-per-workgroup kernel (MI355_MLA_WIDE=0) instead of the 128-heads-per-workgroup one"
+  for a in "64 32 4096" "32 64 4096" "128 128 4096" "256 128 4096" "256 64 4096" "256 32 4096"; do MI355_MLA_WIDE=0 MLA_TARGETS=0,0 timeout -k 10 120 python3 tools/bench_mla.py $a | tail -1; done
   echo "the same rows in randomly placed blocks of 16 tokens, a pool each for c_kv and k_rope (mi355_mla_decode_paged); one pool of R + P wide rows; fp32"
   for a in "64 16 4096" "256 16 4096" "128 128 4096"; do MLA_PAGED=16 MLA_PAGED_SPLIT=1 MLA_TARGETS=0 timeout -k 10 120 python3 tools/bench_mla.py $a | tail -1; done
   MLA_PAGED=16 MLA_TARGETS=0 timeout -k 10 120 python3 tools/bench_mla.py 256 16 4096 | tail -1

@@ -25,10 +25,11 @@ with open(os.path.join(dst, f'{tag}_secondary_benchmarks.txt'), 'w') as f:      
         if os.path.exists(os.path.join(src, part)):
             f.write(open(os.path.join(src, part)).read())
 put('pmc_mla_fetch/fetch_counter_collection.csv', 'pmc_mla_fetch_size.csv')
-for name in ('gqa', 'mla', 'prefill', 'engine', 'prefill_f32', 'c2tune'):
+for name in ('gqa', 'mla', 'mla_wide', 'prefill', 'engine', 'prefill_f32', 'c2tune'):
     put(f'trace_{name}/{name}_kernel_stats.csv', f'{name}_kernel_stats.csv')
 for rel, name in [('engine_decode_step_kernels.txt', 'engine_decode_step_kernels.txt'),
                   ('sampler_phases.txt', 'sampler_phases.txt'),
+                  ('mla_wide_phases.txt', 'mla_wide_phases.txt'),
                   ('trace_exchange/exchange_kernel_stats.csv', 'exchange_kernel_stats.csv'),
                   ('bench_line_exchange_under_rocprof.json', 'bench_line_exchange_under_rocprof.json')]:
     if os.path.exists(os.path.join(src, rel)):
@@ -100,4 +101,16 @@ if c:
                "lds_conflict_fraction": round(c['SQ_LDS_BANK_CONFLICT'] / c['SQ_LDS_IDX_ACTIVE'], 4),
                "wave_wait_fraction (SQ_WAIT_ANY / SQ_WAVE_CYCLES)": round(c['SQ_WAIT_ANY'] / c['SQ_WAVE_CYCLES'], 4)},
               open(os.path.join(dst, f'{tag}_pmc_mla_many_heads.json'), 'w'), indent=1)
+c, n = counters(os.path.join(src, 'pmc_mla_wide/*/*counter_collection.csv'), 'mla_decode_kernel_wide')
+if c:
+    cycles = c['GRBM_GUI_ACTIVE'] / 8
+    json.dump({"kernel": "mla_decode_kernel_wide<BF16, dense>",
+               "workload": "256 rows x 4096 tokens, 128 heads, kv_lora_rank 512, rope 64 (tools/bench_mla.py 256 128 4096)",
+               "launches": n, "counters (average per launch)": {k: round(v) for k, v in sorted(c.items())},
+               "kernel_cycles (GRBM_GUI_ACTIVE summed over 8 XCDs / 8)": round(cycles),
+               "mfma_busy_fraction": round(c['SQ_VALU_MFMA_BUSY_CYCLES'] / (cycles * 1024), 4),
+               "lds_busy_fraction": round(c['SQ_LDS_IDX_ACTIVE'] / (256 * cycles), 4),
+               "lds_conflict_fraction": round(c['SQ_LDS_BANK_CONFLICT'] / c['SQ_LDS_IDX_ACTIVE'], 4),
+               "wave_wait_fraction (SQ_WAIT_ANY / SQ_WAVE_CYCLES)": round(c['SQ_WAIT_ANY'] / c['SQ_WAVE_CYCLES'], 4)},
+              open(os.path.join(dst, f'{tag}_pmc_mla_wide.json'), 'w'), indent=1)
 print(sorted(f for f in os.listdir(dst) if f.startswith(tag)))
