@@ -251,40 +251,70 @@ __global__ void __launch_bounds__(256) MI355_NO_PACKED_F32 mla_decode_kernel_wid
   const int rr = 8 * wave + (lane >> 3);             // the rope row this lane fetches and rotates
   const int rslot = lane & 7, rswz = (rr >> 1) & 7;
   const uint32_t lds0 = (uint32_t)(uintptr_t)lds;   // LDS byte address of the image
-  // piece i of the direct-to-LDS loads of the tile at t0: 0 .. 7 the wave's c_kv rows (rows
-  // w, w + 4, ...), 8 its rope rows.  The byte offset of row w + 4i from the sequence's base is
-  // min(t0 + w, last) * stride + min(4i * stride, rows left behind it * stride): two scalar
-  // instructions per row once the two products are known (TileSrc, once per tile).
+  // piece i of the direct-to-LDS loads of the tile at t0: 0 .. 7 the wave's c_kv rows, 8 its rope rows.
+  // Dense rows: the wave takes rows w, w + 4, ...; the byte offset of row w + 4i from the sequence's
+  // base is min(t0 + w, last) * stride + min(4i * stride, rows left behind it * stride): two scalar
+  // instructions per row once the two products are known (TileSrc, once per tile).  Blocks of >= 8
+  // tokens (kPagedGroups): the wave takes rows 8w .. 8w + 7, which lie in one block -- one table
+  // lookup and one 64-bit base per wave and tile, a row adds min(i, rows left) * stride; a group past
+  // the end of the range is pulled back to the last live one (its rows are masked either way).
+  // Smaller blocks (kPaged): a lookup per row.
   struct TileSrc {
     uint32_t first, room;
+    const char* ckv_base;
+    const char* krope_base;
+    int n_last;
   };
   const uint32_t lane16 = lane * 16;
+  // (LDS addresses of the wave's first row; row 8w + i sits i pitches on, shifted by ((2w + i / 4) mod 4) x 16 B)
+  const uint32_t dst_rows = __builtin_amdgcn_readfirstlane(lds0 + wave * kPitch);
+  const uint32_t dst_grp_a = __builtin_amdgcn_readfirstlane(lds0 + 8 * wave * kPitch + ((2 * wave) & 3) * 16);
+  const uint32_t dst_grp_b = __builtin_amdgcn_readfirstlane(lds0 + 8 * wave * kPitch + ((2 * wave + 1) & 3) * 16);
   auto tile_src = [&](int t0) __attribute__((always_inline)) {
-    const int last = t_end - 1, r0 = min(t0 + wave, last);
-    return TileSrc{(uint32_t)(r0 * cstride2), (uint32_t)((last - r0) * cstride2)};
+    const int last = t_end - 1;
+    TileSrc ts = {};
+    if constexpr (is_grouped(PAGED)) {
+      const int gs = min(t0 + 8 * wave, last & ~7);
+      ts.n_last = min(last - gs, 7);
+      ts.room = (uint32_t)(ts.n_last * cstride2);
+      const int id = __builtin_amdgcn_readfirstlane(
+          *(const __attribute__((address_space(3))) int*)(lds + kIdsOff + 4 * ((gs >> p.bs_shift) - blk0)));
+      const int r0 = gs & p.bs_mask;
+      ts.ckv_base = ckv + ((int64_t)id * p.ckv_stride_blk * 2 + (int64_t)r0 * cstride2);
+      ts.krope_base = krope + ((int64_t)id * p.krope_stride_blk * 2 + (int64_t)r0 * rstride2);
+    } else {
+      const int r0 = min(t0 + wave, last);
+      ts.first = (uint32_t)(r0 * cstride2);
+      ts.room = (uint32_t)((last - r0) * cstride2);
+    }
+    return ts;
   };
   auto issue_piece = [&](auto ic, int t0, const TileSrc& ts, int bufoff) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
     const int last = t_end - 1;
     if constexpr (i < 8) {
-      const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + bufoff + wave * kPitch);
-      if constexpr (is_paged(PAGED)) {
+      if constexpr (is_grouped(PAGED)) {
+        const uint32_t off = min((uint32_t)i * (uint32_t)cstride2, ts.room);
+        to_lds16_rows<i * kPitch>(ts.ckv_base, lane16 + off, (i < 4 ? dst_grp_a : dst_grp_b) + bufoff);
+      } else if constexpr (is_paged(PAGED)) {
         const int tok = min(t0 + wave + 4 * i, last);                 // wave-uniform
         const int id = *(const __attribute__((address_space(3))) int*)(lds + kIdsOff + 4 * ((tok >> p.bs_shift) - blk0));
         const char* src = ckv + ((int64_t)__builtin_amdgcn_readfirstlane(id) * p.ckv_stride_blk * 2 + (int64_t)(tok & p.bs_mask) * cstride2);
-        to_lds16_rows<row_off(4 * i)>(src, lane16, dst);
+        to_lds16_rows<row_off(4 * i)>(src, lane16, dst_rows + bufoff);
       } else {
         const uint32_t off = ts.first + min((uint32_t)(4 * i) * (uint32_t)cstride2, ts.room);
-        to_lds16_rows<row_off(4 * i)>(ckv, lane16 + off, dst);
+        to_lds16_rows<row_off(4 * i)>(ckv, lane16 + off, dst_rows + bufoff);
       }
     } else {
-      const int tokr = min(t0 + rr, last);
       const char* rsrc;
-      if constexpr (is_paged(PAGED)) {
+      if constexpr (is_grouped(PAGED)) {
+        rsrc = ts.krope_base + (uint32_t)(min(lane >> 3, ts.n_last) * rstride2);
+      } else if constexpr (is_paged(PAGED)) {
+        const int tokr = min(t0 + rr, last);
         const int id = *(const __attribute__((address_space(3))) int*)(lds + kIdsOff + 4 * ((tokr >> p.bs_shift) - blk0));
         rsrc = krope + ((int64_t)id * p.krope_stride_blk * 2 + (int64_t)(tokr & p.bs_mask) * rstride2);
       } else {
-        rsrc = krope + (uint32_t)(tokr * rstride2);
+        rsrc = krope + (uint32_t)(min(t0 + rr, last) * rstride2);
       }
       to_lds16_lanes(rsrc + ((rslot ^ rswz) << 4), __builtin_amdgcn_readfirstlane(lds0 + bufoff + kRopeOff + wave * 1024));
     }
@@ -641,6 +671,8 @@ int mla_wide_max_paged_tokens(int block_size) { return kIdsMax * block_size; }
 
 int mla_wide_launch(const void* params, int dtype, bool paged, hipStream_t stream) {
   const MlaParams& p = *static_cast<const MlaParams*>(params);
+  if (paged && p.bs_shift >= 3 && knob(kKnobMlaRowGroups) != 0)   // blocks of >= 8 tokens: a wave's 8 rows of a tile share a block
+    return dtype == MI355_BF16 ? launch_wide<BF16, kPagedGroups>(p, stream) : launch_wide<F16, kPagedGroups>(p, stream);
   if (paged) return dtype == MI355_BF16 ? launch_wide<BF16, kPaged>(p, stream) : launch_wide<F16, kPaged>(p, stream);
   return dtype == MI355_BF16 ? launch_wide<BF16, kDense>(p, stream) : launch_wide<F16, kDense>(p, stream);
 }
