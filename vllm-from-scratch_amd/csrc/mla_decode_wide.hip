@@ -667,7 +667,8 @@ bool mla_wide_supported(int H, int R, int P, int dtype) {
 }
 
 // Most tokens per workgroup a paged launch can hold block ids for (the plan splits longer ranges).
-int mla_wide_max_paged_tokens(int block_size) { return kIdsMax * block_size; }
+// (a range that does not start on a block boundary touches up to two blocks more than tokens / block_size)
+int mla_wide_max_paged_tokens(int block_size) { return (kIdsMax - 2) * block_size; }
 
 int mla_wide_launch(const void* params, int dtype, bool paged, hipStream_t stream) {
   const MlaParams& p = *static_cast<const MlaParams*>(params);
