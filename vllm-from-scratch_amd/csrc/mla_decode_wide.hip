@@ -63,9 +63,10 @@ struct Mma32<F16> {
 // The score product's 32 x 32 accumulator in VGPRs, as asm.  In a kernel that uses AccVGPRs at all
 // this compiler gives EVERY matrix instruction an AccVGPR destination; the 256 of them hold O^T, so
 // a builtin here would spill sixteen of those around every tile.  The compiler does not see these
-// as matrix instructions: the last one of a chain carries the wait states a VALU read of the
-// result needs (16 passes + 2), and dependent steps of the chain reuse the same registers, which
-// the matrix pipe forwards without wait states.
+// as matrix instructions: where the VALU reads a chain's result right away (the first tile's, LAST)
+// the last instruction carries the wait states that read needs (16 passes + 2) -- in the loop a whole
+// value product lies between a chain and its readers --, and dependent steps of the chain reuse the
+// same registers, which the matrix pipe forwards without wait states.
 template <class Tag, bool FIRST, bool LAST>
 __device__ __forceinline__ void score_mma(f32x16& acc, u32x4 a, u32x4 b) {
   if constexpr (std::is_same<Tag, BF16>::value) {
@@ -245,9 +246,10 @@ __global__ void __launch_bounds__(256) MI355_NO_PACKED_F32 mla_decode_kernel_wid
   }
   const int blk0 = t_begin >> p.bs_shift;
 
-  // One tile's loads.  c_kv: wave w fetches rows w, w + 4, ... (one row = one 64-lane load); rope
-  // parts and the cos / sin rows of the same tokens: wave w fetches rows 8w .. 8w + 7, eight lanes a
-  // row.  Rows past the end of the range re-read its last row (their scores are masked).
+  // One tile's loads.  c_kv: one row = one 64-lane load straight into LDS, eight rows per wave;
+  // rope parts: wave w fetches those of rows 8w .. 8w + 7 with one such load, eight lanes a row, and
+  // every lane the cos / sin columns of its four pairs of its row, into registers.  Rows past the
+  // end of the range re-read its last rows (their scores are masked).
   const int rr = 8 * wave + (lane >> 3);             // the rope row this lane fetches and rotates
   const int rslot = lane & 7, rswz = (rr >> 1) & 7;
   const uint32_t lds0 = (uint32_t)(uintptr_t)lds;   // LDS byte address of the image
