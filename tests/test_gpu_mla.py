@@ -534,7 +534,8 @@ def test_wide_kernel_matches_64_head_kernel_and_oracle(ops, device, shape, dtype
     cos, sin = mo.rope_tables(P, S)
     args = (q.to(device), c_kv.to(device), k_rope.to(device), torch.from_numpy(cos).to(device),
             torch.from_numpy(sin).to(device), torch.from_numpy(ctx).to(device), S, 0.07)
-    wide = ops.mla_decode(*args).cpu().numpy()
+    with ops.debug_knob('MI355_MLA_WIDE_SPLIT_TOKENS', 1):      # (the plan leaves short token splits to the 64-head kernel)
+        wide = ops.mla_decode(*args).cpu().numpy()
     with ops.debug_knob('MI355_MLA_WIDE', 0):
         ref = ops.mla_decode(*args).cpu().numpy()
     assert not np.isnan(wide).any()
@@ -569,8 +570,9 @@ def test_wide_kernel_scores_that_keep_growing(ops, device):
     cos, sin = mo.rope_tables(P, S)
     scale = 1.5
     want = mo.latent_attention(q.float().numpy(), c_kv.float().numpy(), k_rope.float().numpy(), cos, sin, ctx, scale)
-    out = ops.mla_decode(q.to(device), c_kv.to(device), k_rope.to(device), torch.from_numpy(cos).to(device),
-                         torch.from_numpy(sin).to(device), torch.from_numpy(ctx).to(device), S, scale)
+    with ops.debug_knob('MI355_MLA_WIDE_SPLIT_TOKENS', 1):
+        out = ops.mla_decode(q.to(device), c_kv.to(device), k_rope.to(device), torch.from_numpy(cos).to(device),
+                             torch.from_numpy(sin).to(device), torch.from_numpy(ctx).to(device), S, scale)
     np.testing.assert_allclose(out.cpu().numpy(), want, **TOL[torch.bfloat16])
 
 
@@ -593,10 +595,11 @@ def test_wide_kernel_paged_equals_dense(ops, device, shape, dtype):
     cos, sin = mo.rope_tables(P, S + 3)
     pool, bt = _scatter_into_blocks(rng, c_kv, k_rope, bs)
     cos_d, sin_d, ctx_d = torch.from_numpy(cos).to(device), torch.from_numpy(sin).to(device), torch.from_numpy(ctx).to(device)
-    dense = ops.mla_decode(q.to(device), c_kv.to(device), k_rope.to(device), cos_d, sin_d, ctx_d, max_ctx, 0.11)
-    pool_d = pool.to(device)
-    paged = ops.mla_decode_paged(q.to(device), pool_d[..., :R], pool_d[..., R:], torch.from_numpy(bt).to(device),
-                                 cos_d, sin_d, ctx_d, max_ctx, 0.11)
+    with ops.debug_knob('MI355_MLA_WIDE_SPLIT_TOKENS', 1):
+        dense = ops.mla_decode(q.to(device), c_kv.to(device), k_rope.to(device), cos_d, sin_d, ctx_d, max_ctx, 0.11)
+        pool_d = pool.to(device)
+        paged = ops.mla_decode_paged(q.to(device), pool_d[..., :R], pool_d[..., R:], torch.from_numpy(bt).to(device),
+                                     cos_d, sin_d, ctx_d, max_ctx, 0.11)
     torch.cuda.synchronize()
     assert not torch.isnan(paged).any()
     if bs * 1982 > max_ctx:

@@ -41,6 +41,7 @@ enum Knob {
   kKnobDpExchangeProbe,   // MI355_DP_EXCHANGE_PROBE   measurement only, bit mask: 1 no collective, 2 no completion event, 4 no watcher
   kKnobMlaRowGroups,      // MI355_MLA_ROW_GROUPS      1: paged rank-512 MLA tiles staged as 8 consecutive rows per wave
   kKnobMlaWide,           // MI355_MLA_WIDE            fewest heads served by the 128-heads-per-workgroup MLA kernel (rank 512, rope 64); 0: off
+  kKnobMlaWideSplitTokens,  // MI355_MLA_WIDE_SPLIT_TOKENS  fewest tokens per workgroup at which a launch with token splits takes the 128-head kernel (0: planned)
   kKnobCount
 };
 int knob(Knob k);

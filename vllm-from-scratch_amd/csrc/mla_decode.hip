@@ -882,20 +882,35 @@ int mla_plan(int rows, int H, int R, int P, int max_context, int dtype, MlaPlan*
   MlaPlan pl;
   pl.many = R >= 128 && H > kHeadTile && knob(kKnobMlaManyHeads) != 0;   // 64 heads per workgroup
   pl.wide = pl.many && mla_wide_supported(H, R, P, dtype);
-  pl.n_ht = pl.wide ? (H + 127) / 128 : pl.many ? (H + 4 * kHeadTile - 1) / (4 * kHeadTile) : (H + kHeadTile - 1) / kHeadTile;
   const int ctx = max_context > 0 ? max_context : 1;
-  const int64_t base = (int64_t)rows * pl.n_ht;
   // one-wave kernel (R < 128): 8 workgroups per CU.  Four-wave kernel: one workgroup per CU
   // before tokens are split -- with two tiles of prefetch per workgroup, few long workgroups
   // beat many short ones (measured at 256 rows x 4096 tokens: 187 us unsplit, 193 us with 2
   // splits, 212 us with 4).
   const int target = knob(kKnobMlaTargetWgs) > 0 ? knob(kKnobMlaTargetWgs) : (R >= 128 ? 256 : 2048);
-  int64_t want = ceil_div64(target, base);
-  const int64_t most = ctx / 128 > 0 ? ctx / 128 : 1;           // at least 4 steps per workgroup
-  if (want > most) want = most;
-  if (want < 1) want = 1;
-  pl.tps = (int)(ceil_div64(ceil_div64(ctx, want), kTok2) * kTok2);
-  pl.nsplit = (int)ceil_div64(ctx, pl.tps);
+  auto split_tokens = [&]() {
+    pl.n_ht = pl.wide ? (H + 127) / 128 : pl.many ? (H + 4 * kHeadTile - 1) / (4 * kHeadTile) : (H + kHeadTile - 1) / kHeadTile;
+    int64_t want = ceil_div64(target, (int64_t)rows * pl.n_ht);
+    const int64_t most = ctx / 128 > 0 ? ctx / 128 : 1;           // at least 4 steps per workgroup
+    if (want > most) want = most;
+    if (want < 1) want = 1;
+    pl.tps = (int)(ceil_div64(ceil_div64(ctx, want), kTok2) * kTok2);
+    pl.nsplit = (int)ceil_div64(ctx, pl.tps);
+  };
+  split_tokens();
+  // The 128-heads-per-workgroup kernel starts with three tiles of loads and the queries of 128 heads,
+  // and with one head tile where the 64-head kernel has two it needs twice the token splits (and
+  // twice the records to merge) to fill the chip: small batches are the 64-head kernel's.  Measured
+  // (128 heads): 1 row x 32768 tokens 133 vs 77 us, 16 rows x 4096 66.5 vs 52.3, 4 rows x 32768 89.8 vs
+  // 84.8; 16 rows x 8192 and 32 rows x 4096 (512 tokens per workgroup) a tie; 32 heads, 8 rows x 8192
+  // (256 tokens per workgroup, the same splits for both kernels): 39.8 vs 41.9.
+  if (pl.wide && pl.nsplit > 1) {
+    const int least = knob(kKnobMlaWideSplitTokens) > 0 ? knob(kKnobMlaWideSplitTokens) : (H > 64 ? 1024 : 256);
+    if (pl.tps < least) {
+      pl.wide = false;
+      split_tokens();
+    }
+  }
   pl.ws_bytes = pl.nsplit > 1 ? (size_t)rows * H * pl.nsplit * (R + 2) * sizeof(float) : 0;
   *out = pl;
   return 0;
