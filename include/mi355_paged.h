@@ -491,7 +491,7 @@ int mi355_dp_exchange_destroy(void* exchange);
  * The launch plans have a few integer knobs kept switchable so that two variants can be compared
  * inside one process: MI355_DECODE_GQA_MFMA, MI355_PAGED_TARGET_WGS, MI355_PAGED_HPW,
  * MI355_PAGED_PREFILL_MIN_Q, MI355_PREFILL_VALU, MI355_PREFILL_F32_TILED, MI355_PREFILL_ROW_GROUPS,
- * MI355_PREFILL_WAVES, MI355_MLA_MANY_HEADS, MI355_MLA_TARGET_WGS, MI355_MLA_ROW_GROUPS, MI355_MLA_WIDE, MI355_MLA_WIDE_SPLIT_TOKENS, MI355_PREFILL_F32_MFMA,
+ * MI355_PREFILL_WAVES, MI355_MLA_MANY_HEADS, MI355_MLA_TARGET_WGS, MI355_MLA_ROW_GROUPS, MI355_MLA_WIDE, MI355_MLA_WIDE_SPLIT_TOKENS, MI355_MLA_WIDE_FUSED_MERGE, MI355_MLA_WIDE_SKEW_TOKENS, MI355_PREFILL_F32_MFMA,
  * MI355_DECODE_FUSED_MERGE, MI355_PAGED_BALANCE_WGS, MI355_DP_EXCHANGE_PROBE.  Each takes its default, or the
  * value of the environment variable of the same name, which the library reads ONCE per process;
  * afterwards only this call changes it (value INT32_MIN restores the process's start-up value).

@@ -606,3 +606,96 @@ def test_wide_kernel_paged_equals_dense(ops, device, shape, dtype):
         assert torch.equal(paged.view(torch.int32), dense.view(torch.int32))
     else:
         np.testing.assert_allclose(paged.cpu().numpy(), dense.cpu().numpy(), **TOL[dtype])
+
+
+def _where_unequal(got, want):
+    idx = (got.view(torch.int32) != want.view(torch.int32)).nonzero()
+    if not len(idx):
+        return 'equal'
+    r, hh, d = idx[0].tolist()
+    return (f"{len(idx)} values in rows {sorted(set(idx[:, 0].tolist()))[:8]}, heads {sorted(set(idx[:, 1].tolist()))[:16]}, "
+            f"dims {int(idx[:, 2].min())}..{int(idx[:, 2].max())}; first ({r}, {hh}, {d}): {float(got[r, hh, d])} vs {float(want[r, hh, d])}")
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape', [(3, 128, 2100, 6, 0), (5, 40, 700, 10, 0), (2, 200, 1300, 8, 0), (4, 128, 4096, 8, 16),
+                                   (128, 128, 2300, 0, 0)])
+def test_wide_kernel_merges_two_token_splits_in_the_launch(ops, device, shape, dtype):
+    """Two token splits of the 128-heads-per-workgroup kernel: the workgroup of a pair that finishes
+    later combines its registers with the other's record (MI355_MLA_WIDE_FUSED_MERGE, the default) --
+    bit for bit what the merge kernel makes of the two records (knob = 0), call after call on one
+    workspace whose contents are scrambled in between (the arrival cells must not depend on what it
+    held), rows whose second split is empty, an empty row, over a block cache, and replays of one
+    captured launch; and, within tolerance, with the first split shortened (the default: the second
+    workgroup then finds the first one's record written and writes none itself)."""
+    seqs, H, S, target, bs = shape
+    R, P = 512, 64
+    g = torch.Generator(device=device).manual_seed(seqs + H + S)
+    c_kv = torch.randn((seqs, S, R), generator=g, device=device).to(dtype)
+    k_rope = torch.randn((seqs, S, P), generator=g, device=device).to(dtype)
+    cos, sin = (torch.from_numpy(x).to(device) for x in mo.rope_tables(P, S))
+    if bs:
+        per = -(-S // bs)
+        order = torch.randperm(seqs * per, generator=g, device=device)
+        pool = torch.zeros((seqs * per, bs, R + P), dtype=dtype, device=device)
+        rows = torch.nn.functional.pad(torch.cat((c_kv, k_rope), -1), (0, 0, 0, per * bs - S))
+        pool[order] = rows.view(seqs * per, bs, R + P)
+        bt = order.view(seqs, per).to(torch.int32).contiguous()
+
+    def call(q, ctx, out=None):
+        if bs:
+            return ops.mla_decode_paged(q, pool[..., :R], pool[..., R:], bt, cos, sin, ctx, S, 0.09, out=out)
+        return ops.mla_decode(q, c_kv, k_rope, cos, sin, ctx, S, 0.09, out=out)
+
+    code = ops._DTYPE_CODE[dtype]
+    stream = torch.cuda.current_stream(device).cuda_stream
+    def even(q, ctx, out=None):     # the two splits where the merge kernel's plan puts them
+        with ops.debug_knob('MI355_MLA_WIDE_SKEW_TOKENS', 0):
+            return call(q, ctx, out=out)
+
+    with ops.debug_knob('MI355_MLA_WIDE_SPLIT_TOKENS', 1), ops.debug_knob('MI355_MLA_TARGET_WGS', target):
+        need = ops._lib.load().mi355_mla_decode_workspace_bytes(seqs, H, R, P, S, code)
+        with ops.debug_knob('MI355_MLA_WIDE_FUSED_MERGE', 0):
+            plain = ops._lib.load().mi355_mla_decode_workspace_bytes(seqs, H, R, P, S, code)
+        assert need == plain + seqs * ((H + 127) // 128) * 8, "the case is meant to run two splits, merged in the launch"
+        for it in range(8):
+            q = (torch.randn((seqs, H, R + P), generator=g, device=device) * 0.4).to(dtype)
+            ctx = torch.randint(1, S + 1, (seqs,), generator=g, device=device).to(torch.int32)
+            ctx[it % seqs] = S if it % 3 else 0
+            ctx[(it + 1) % seqs] = 1 + it
+            with ops.debug_knob('MI355_MLA_WIDE_FUSED_MERGE', 0):
+                want = call(q, ctx)
+            ws, _ = ops._workspace(device, need, stream)
+            if it % 4 == 0:
+                ws.zero_()
+            elif it % 4 == 1:
+                ws.fill_(255)
+            elif it % 4 == 2:
+                ws.view(torch.int64)[:need // 8].random_(-2 ** 62, 2 ** 62, generator=g)
+            got = even(q, ctx)
+            assert torch.equal(got.view(torch.int32), want.view(torch.int32)), f"call {it}: {_where_unequal(got, want)}"
+            assert not got[it % seqs].abs().sum().item() if not it % 3 else True
+            # split 0 shortened so that only one workgroup of a pair writes a record: other split
+            # points, the same attention
+            with ops.debug_knob('MI355_MLA_WIDE_SKEW_TOKENS', 64 if it % 2 else 160):
+                skewed = call(q, ctx)
+            np.testing.assert_allclose(skewed.cpu().numpy(), want.cpu().numpy(), **TOL[dtype])
+
+        q = (torch.randn((seqs, H, R + P), generator=g, device=device) * 0.4).to(dtype)
+        ctx = torch.full((seqs,), S, dtype=torch.int32, device=device)
+        out = torch.empty((seqs, H, R), dtype=torch.float32, device=device)
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            even(q, ctx, out=out)
+        torch.cuda.current_stream(device).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            even(q, ctx, out=out)
+        for it in range(4):
+            q.copy_((torch.randn((seqs, H, R + P), generator=g, device=device) * 0.4).to(dtype))
+            ctx.copy_(torch.randint(1, S + 1, (seqs,), generator=g, device=device).to(torch.int32))
+            graph.replay()
+            with ops.debug_knob('MI355_MLA_WIDE_FUSED_MERGE', 0):
+                want = call(q, ctx)
+            assert torch.equal(out.view(torch.int32), want.view(torch.int32)), f"replay {it}"

@@ -28,3 +28,9 @@ torch.cuda.synchronize()
 t = out.view(-1)[:8].view(torch.int64).cpu().tolist()
 n = max(t[3], 1)
 print(f'steps {t[3]}: per step  barrier {t[0] / n:.0f}  score phase {t[1] / n:.0f}  value phase {t[2] / n:.0f}  total {(t[0] + t[1] + t[2]) / n:.0f} shader-clock ticks')
+t = out.view(-1)[:160].view(torch.int64).cpu().tolist()
+base = min(x for x in t[9:80:8] if x > 0)
+for b in range(8):     # the epilogues of workgroups 0 .. 7 on the 100 MHz clock, in microseconds from the earliest loop end
+    e = t[8 + 8 * b:16 + 8 * b]
+    print(f'workgroup {b}: row {e[0] >> 8} split {e[0] & 255}  loop end {(e[1] - base) / 100:.2f}  records issued +{(e[2] - e[1]) / 100:.2f}'
+          f'  acknowledged +{(e[3] - e[2]) / 100:.2f}  counted +{(e[4] - e[3]) / 100:.2f}  done +{(e[5] - e[4]) / 100:.2f} us')

@@ -38,7 +38,8 @@ const KnobDef kKnobDefs[kKnobCount] = {
     {"MI355_PREFILL_ROW_GROUPS", 1}, {"MI355_PREFILL_WAVES", 0},     {"MI355_MLA_MANY_HEADS", 1},
     {"MI355_MLA_TARGET_WGS", 0},      {"MI355_PREFILL_F32_MFMA", 1},    {"MI355_DECODE_FUSED_MERGE", 8},
     {"MI355_PAGED_BALANCE_WGS", 2048}, {"MI355_DP_EXCHANGE_PROBE", 0},  {"MI355_MLA_ROW_GROUPS", 1},
-    {"MI355_MLA_WIDE", 17},          {"MI355_MLA_WIDE_SPLIT_TOKENS", 0},
+    {"MI355_MLA_WIDE", 17},          {"MI355_MLA_WIDE_SPLIT_TOKENS", 0}, {"MI355_MLA_WIDE_FUSED_MERGE", 1},
+    {"MI355_MLA_WIDE_SKEW_TOKENS", 96},
 };
 std::atomic<int> g_knob[kKnobCount];
 int g_knob_start[kKnobCount];   // the process's values: defaults overridden by the environment

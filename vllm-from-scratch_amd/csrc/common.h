@@ -42,6 +42,8 @@ enum Knob {
   kKnobMlaRowGroups,      // MI355_MLA_ROW_GROUPS      1: paged rank-512 MLA tiles staged as 8 consecutive rows per wave
   kKnobMlaWide,           // MI355_MLA_WIDE            fewest heads served by the 128-heads-per-workgroup MLA kernel (rank 512, rope 64); 0: off
   kKnobMlaWideSplitTokens,  // MI355_MLA_WIDE_SPLIT_TOKENS  fewest tokens per workgroup at which a launch with token splits takes the 128-head kernel (0: planned)
+  kKnobMlaWideFusedMerge,   // MI355_MLA_WIDE_FUSED_MERGE   1: two token splits of the 128-head kernel are merged by the later workgroup of the pair (0: by the merge kernel)
+  kKnobMlaWideSkewTokens,   // MI355_MLA_WIDE_SKEW_TOKENS   tokens split 0 of such a pair is given less than half (so that only one record is written); 0: even splits
   kKnobCount
 };
 int knob(Knob k);
@@ -77,6 +79,9 @@ void mla_f32_plan(int rows, int H, int max_context, int* nsplit, int* tps, size_
 bool mla_wide_supported(int H, int R, int P, int dtype);
 int mla_wide_max_paged_tokens(int block_size);
 int mla_wide_launch(const void* params, int dtype, bool paged, hipStream_t stream);
+// A 48-bit tag that differs for every launch of this process (paged_decode.hip): arrival cells in a
+// caller's workspace count only while they carry the launch's tag, so the workspace needs no clearing.
+unsigned long long next_launch_tag();
 // Combines token-split partials [rows, H, nsplit, R] + (max, sum) records into out (mla_decode.hip).
 int mla_merge_launch(float* out, float* ws_acc, float* ws_ml, const int32_t* ctx, int rows, int H, int R,
                      int max_ctx, int nsplit, int tps, hipStream_t stream);

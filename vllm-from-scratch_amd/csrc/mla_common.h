@@ -35,6 +35,10 @@ struct MlaParams {
   const int32_t* bt = nullptr;   // [sequences, max_blocks]
   int64_t ckv_stride_blk = 0, krope_stride_blk = 0;
   int bs_shift = 0, bs_mask = 0, max_blocks = 0, num_blocks = 0;
+  // Two token splits merged inside the launch (128-heads-per-workgroup kernel): an arrival cell per
+  // (row, head tile) behind the records, counting while it holds (epoch << 16); null: merge kernel.
+  unsigned long long* counters = nullptr;
+  unsigned long long epoch = 0;
 };
 
 // Addressing modes of the kernels below (template parameter PAGED).

@@ -867,6 +867,8 @@ __global__ void __launch_bounds__(256) mla_merge_kernel(const MlaParams p) {
 struct MlaPlan {
   bool many;
   bool wide;   // 128 heads per workgroup (mla_decode_wide.hip)
+  bool fused;  // ... and its two token splits merged inside the launch
+  int skew;    // ... of which split 0 then takes this many tokens fewer than tps, split 1 the rest
   int n_ht, nsplit, tps;
   size_t ws_bytes;
 };
@@ -891,6 +893,16 @@ int mla_plan(int rows, int H, int R, int P, int max_context, int dtype, MlaPlan*
   auto split_tokens = [&]() {
     pl.n_ht = pl.wide ? (H + 127) / 128 : pl.many ? (H + 4 * kHeadTile - 1) / (4 * kHeadTile) : (H + kHeadTile - 1) / kHeadTile;
     int64_t want = ceil_div64(target, (int64_t)rows * pl.n_ht);
+    // The four-wave kernels run one workgroup per CU: a 257th workgroup waits for a whole one to
+    // finish, so the split count is rounded down (96 rows x 128 heads x 4096 tokens: 195 us in 3 splits,
+    // 138 in 2; 64-head kernel, 24 rows: 109 -> 69 us; 16 heads, 48 / 96 rows: 65.5 -> 48.6 / 111.8 ->
+    // 92.0).  The 16-head kernel is bound by memory, where a short second round costs less than
+    // CUs left idle: it keeps two splits where rounding down would leave none (130 rows: 154.5
+    // against 166.1 us unsplit; the 128-head kernel at 160 rows: 274 against 225 unsplit).
+    if (R >= 128 && knob(kKnobMlaTargetWgs) <= 0) {
+      const int64_t down = target / ((int64_t)rows * pl.n_ht);
+      if (pl.many || down >= 2) want = down;
+    }
     const int64_t most = ctx / 128 > 0 ? ctx / 128 : 1;           // at least 4 steps per workgroup
     if (want > most) want = most;
     if (want < 1) want = 1;
@@ -900,18 +912,32 @@ int mla_plan(int rows, int H, int R, int P, int max_context, int dtype, MlaPlan*
   split_tokens();
   // The 128-heads-per-workgroup kernel starts with three tiles of loads and the queries of 128 heads,
   // and with one head tile where the 64-head kernel has two it needs twice the token splits (and
-  // twice the records to merge) to fill the chip: small batches are the 64-head kernel's.  Measured
-  // (128 heads): 1 row x 32768 tokens 133 vs 77 us, 16 rows x 4096 66.5 vs 52.3, 4 rows x 32768 89.8 vs
-  // 84.8; 16 rows x 8192 and 32 rows x 4096 (512 tokens per workgroup) a tie; 32 heads, 8 rows x 8192
-  // (256 tokens per workgroup, the same splits for both kernels): 39.8 vs 41.9.
+  // twice the records to merge) to fill the chip: the smallest batches are the 64-head kernel's.
+  // Measured at 128 heads x 4096 tokens, wide against 64-head (us): 24 rows (416 tokens per
+  // workgroup) 58.4 / 69.3, 20 rows (352) 55.3 / 62.2, 16 rows (256) 52.3 / 52.1, 8 rows 46.2 / 41.3,
+  // 1 row x 32768 tokens 123 / 77; 32 heads, 8 rows x 8192 (256 tokens per workgroup, the same splits
+  // for both kernels): 39.8 / 41.9.
   if (pl.wide && pl.nsplit > 1) {
-    const int least = knob(kKnobMlaWideSplitTokens) > 0 ? knob(kKnobMlaWideSplitTokens) : (H > 64 ? 1024 : 256);
+    const int least = knob(kKnobMlaWideSplitTokens) > 0 ? knob(kKnobMlaWideSplitTokens) : (H > 64 ? 320 : 256);
     if (pl.tps < least) {
       pl.wide = false;
       split_tokens();
     }
   }
   pl.ws_bytes = pl.nsplit > 1 ? (size_t)rows * H * pl.nsplit * (R + 2) * sizeof(float) : 0;
+  // Two splits of the wide kernel: the later workgroup of a pair still holds its own partial in
+  // registers, reads the other's record and writes the output row -- a third of the merge kernel's
+  // traffic and no second launch.  (R + 2 is even: the cells behind the records are 8-byte aligned.)
+  pl.fused = pl.wide && pl.nsplit == 2 && knob(kKnobMlaWideFusedMerge) != 0;
+  if (pl.fused) pl.ws_bytes += (size_t)rows * pl.n_ht * sizeof(unsigned long long);
+  // Split 0 is given fewer tokens: its record is then in memory by the time split 1 is done, which
+  // finds the pair's cell counted and combines without writing a record of its own.  All 256
+  // workgroups writing records at once are bound by HBM (67 MB at 128 rows x 128 heads: 12 us).
+  pl.skew = 0;
+  if (pl.fused) {
+    const int skew = (knob(kKnobMlaWideSkewTokens) + kTok2 - 1) / kTok2 * kTok2;
+    if (skew > 0 && pl.tps >= 8 * skew) pl.skew = skew;
+  }
   *out = pl;
   return 0;
 }
@@ -927,8 +953,14 @@ int launch_tail(const MlaParams& p, hipStream_t s) {
   return 0;
 }
 
-int launch_wide_then_merge(const MlaParams& p, int R, int dtype, bool paged, hipStream_t s) {
+int launch_wide_then_merge(MlaParams& p, int R, int dtype, bool paged, bool fused, int skew, hipStream_t s) {
+  if (fused) {
+    p.tps -= skew;
+    p.counters = reinterpret_cast<unsigned long long*>(p.ws_ml + (size_t)p.rows * p.H * p.nsplit * 2);
+    p.epoch = next_launch_tag();
+  }
   if (int rc = mla_wide_launch(&p, dtype, paged, s)) return rc;
+  if (p.counters) return 0;   // merged inside the launch
   return R == 512 ? launch_tail<512>(p, s) : fail(MI355_EUNSUPPORTED, "mla_decode: wide kernel at rank %d", R);
 }
 
@@ -1109,13 +1141,13 @@ int mla_decode_impl(const char* what, float* out, const void* q, int64_t q_strid
     // The wide kernel holds its token range's block ids in LDS and takes its row maxima on the
     // unscaled scores; a longer range (tiny blocks) or a scale that is not positive goes to the
     // 64-head kernel, with the same token splits and so the same workspace.
-    if (pl.wide && scale > 0.f && p.tps < mla_wide_max_paged_tokens(pg.block_size) && ckv_stride_tok < (1 << 26) &&
+    if (pl.wide && scale > 0.f && p.tps + pl.skew < mla_wide_max_paged_tokens(pg.block_size) && ckv_stride_tok < (1 << 26) &&
         krope_stride_tok < (1 << 26))
-      return launch_wide_then_merge(p, R, dtype, true, s);
+      return launch_wide_then_merge(p, R, dtype, true, pl.fused, pl.skew, s);
     if (pl.wide) p.n_ht = (H + 4 * kHeadTile - 1) / (4 * kHeadTile);
     return dtype == MI355_BF16 ? launch_t<BF16, kPaged>(R, p, pl.many, s) : launch_t<F16, kPaged>(R, p, pl.many, s);
   }
-  if (pl.wide && scale > 0.f) return launch_wide_then_merge(p, R, dtype, false, s);
+  if (pl.wide && scale > 0.f) return launch_wide_then_merge(p, R, dtype, false, pl.fused, pl.skew, s);
   if (pl.wide) p.n_ht = (H + 4 * kHeadTile - 1) / (4 * kHeadTile);
   return dtype == MI355_BF16 ? launch_t<BF16, kDense>(R, p, pl.many, s) : launch_t<F16, kDense>(R, p, pl.many, s);
 }

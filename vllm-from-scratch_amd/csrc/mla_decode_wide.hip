@@ -155,10 +155,25 @@ __device__ __forceinline__ void to_lds16_lanes(const void* src, uint32_t dst) {
 __device__ __forceinline__ void load16_uncounted(f32x4& dst, const float* src) {
   asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(src) : "memory");
 }
+// 16 bytes per lane written through to / read from device-coherent memory (sc1: neither left dirty
+// in, nor served from a stale line of, the XCD's L2): what two workgroups of one launch hand each
+// other.  Address = base (wave-uniform, in SGPRs) + voff.  Uncounted like the loads above; a loaded
+// value may be used only behind a wait that names it.
+__device__ __forceinline__ void store16_coherent(float* base, uint32_t voff, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(voff), "v"(v), "s"(base) : "memory");
+}
+__device__ __forceinline__ void load16_coherent(f32x4& dst, const float* base, uint32_t voff) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=&v"(dst) : "v"(voff), "s"(base) : "memory");
+}
 template <int LEFT_IN_FLIGHT>
 __device__ __forceinline__ void wait_loads(f32x4& a, f32x4& b) {
   // (a side build without the direct-to-LDS loads has nothing behind the register loads to count)
   asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"((WIDE_KO & 16) ? 0 : LEFT_IN_FLIGHT) : "memory");
+}
+
+// x of lane `l` (wave-uniform), in every lane.
+__device__ __forceinline__ float lane_value(float x, int l) {
+  return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(x), l));
 }
 
 __device__ __forceinline__ void pair_values(float x, float& lo, float& hi) {
@@ -207,8 +222,18 @@ __global__ void __launch_bounds__(256) MI355_NO_PACKED_F32 mla_decode_kernel_wid
   const int seq = p.row_seq ? p.row_seq[row] : row;
   const int ctx = max(0, min(p.ctx[row], p.max_ctx));
   const int t_begin = sp * p.tps;
-  if (p.nsplit > 1 && t_begin >= ctx) return;
-  const int t_end = min(ctx, t_begin + p.tps);
+  // Two token splits merged in this launch (p.counters): the workgroup of a pair that finishes later
+  // combines its registers with the other's record.  Split 0 marks the pair's arrival cell as this
+  // launch's when it starts, and writes the row itself when split 1 holds no tokens.
+  const bool fused = p.counters != nullptr;
+  const int nvalid = min(p.nsplit, (ctx + p.tps - 1) / p.tps);   // splits that hold tokens
+  if (p.nsplit > 1 && t_begin >= ctx && !(fused && sp == 0)) return;
+  if (fused && sp == 0 && tid == 0)
+    (void)__hip_atomic_fetch_max(p.counters + (int64_t)row * p.n_ht + ht, p.epoch << 16, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+  // (merged in the launch, split 1 takes what split 0 leaves: the plan gives split 0 fewer tokens, so
+  // that its record is out when split 1 is done and only one of the pair writes one)
+  const int t_end = fused && sp == 1 ? ctx : min(ctx, t_begin + p.tps);
   const int head = ht * 128 + wave * 32 + c;          // this lane's head: a column of S^T and of O^T
   const bool head_ok = head < p.H;
   const bool wave_live = ht * 128 + wave * 32 < p.H;  // else the wave only helps staging
@@ -392,6 +417,12 @@ __global__ void __launch_bounds__(256) MI355_NO_PACKED_F32 mla_decode_kernel_wid
   }
 #else
 #define WIDE_STAMP(acc)
+#endif
+#if WIDE_TIMING
+  unsigned long long te[6] = {};   // the epilogue's phases on the 100 MHz clock
+#define WIDE_STAMP_END(k) te[k] = __builtin_amdgcn_s_memrealtime();
+#else
+#define WIDE_STAMP_END(k)
 #endif
   // Per-lane LDS offsets of the operands (buffer offset added per tile).
   const int k_lane = row_off(c) + h * 16;                                  // K operand, latent k-steps: + 32 ks
@@ -610,36 +641,197 @@ __global__ void __launch_bounds__(256) MI355_NO_PACKED_F32 mla_decode_kernel_wid
     pair_values(l_run, a, b);
     l_run = a + b;
   }
-  if (!head_ok) return;
-  // lane (c, h) holds O[head c][32 db + 8 (i / 4) + 4 h + i % 4] in o[db][i]
-  float* dst;
-  float inv = 1.f;
-  if (p.nsplit == 1) {
-    inv = l_run > 0.f ? 1.f / l_run : 0.f;
-    dst = p.out + ((int64_t)row * p.H + head) * kR + 4 * h;
+  WIDE_STAMP_END(0)
+  // ---- Output.  Lane (c, h) holds O[head c][32 db + 8 (i / 4) + 4 h + i % 4] in o[db][i]: stored from
+  // there, one instruction would touch 32 rows with 32 bytes each.  The tile buffers are free now, so
+  // each wave turns its 32 heads x 512 dims around in its own buffer, 256 dims at a time (rows at a
+  // pitch of 1040 bytes: the sixteen lanes of a write phase hit sixteen different bank quads), and
+  // stores whole rows: 1 KiB contiguous per instruction.
+  const bool direct = p.nsplit == 1 || (fused && nvalid < 2);
+  const bool through = fused && !direct;            // records another workgroup of this launch reads
+  // Has the other workgroup of the pair been counted already?  Then this one combines, and its own
+  // record is never read: it is not written.  (Asked here, read after half a staging pass.)
+  unsigned long long cell_seen = 0;
+  if (through && tid == 0)
+    cell_seen = __hip_atomic_load(p.counters + (int64_t)row * p.n_ht + ht, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __builtin_amdgcn_s_barrier();   // every wave is done with the tiles
+  constexpr int kStagePitch = 1040;
+  static_assert(32 * kStagePitch <= kBufBytes - 16, "a wave's half output fits in one tile buffer");
+  lds_byte_t* const stage = lds + wave * kBufBytes;
+  typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+  auto stage_half = [&](auto hc) __attribute__((always_inline)) {
+    constexpr int hf = decltype(hc)::value;
+#pragma unroll
+    for (int dbl = 0; dbl < kDB / 2; ++dbl)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int db = hf * (kDB / 2) + dbl;
+        *(lds_f32x4*)(stage + c * kStagePitch + (32 * dbl + 8 * g4 + 4 * h) * 4) =
+            f32x4{o[db][4 * g4], o[db][4 * g4 + 1], o[db][4 * g4 + 2], o[db][4 * g4 + 3]};
+      }
+  };
+  auto staged_row = [&](int r) __attribute__((always_inline)) { return *(lds_f32x4*)(stage + r * kStagePitch + lane * 16); };
+  const int head0 = ht * 128 + wave * 32;           // this wave's heads: head0 .. head0 + 31
+  const int nheads = min(32, p.H - head0);          // (<= 0: a wave without heads)
+  volatile __attribute__((address_space(3))) int* flag =
+      (volatile __attribute__((address_space(3))) int*)(lds + 4 * kBufBytes - 16);   // (past wave 3's staged rows)
+  bool other_in = false;
+  if (direct) {
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    float* dst = p.out + ((int64_t)row * p.H + head0) * kR + 4 * lane;
+    static_for<0, 2>([&](auto hc) __attribute__((always_inline)) {
+      if (nheads > 0) stage_half(hc);
+#pragma unroll
+      for (int r = 0; r < 32; ++r)
+        if (r < nheads)
+          *reinterpret_cast<f32x4*>(dst + (int64_t)r * kR + 256 * decltype(hc)::value) = staged_row(r) * lane_value(inv, r);
+    });
   } else {
-    const int64_t rec = ((int64_t)row * p.H + head) * p.nsplit + sp;
-    dst = p.ws_acc + rec * kR + 4 * h;
-    if (h == 0) {
-      p.ws_ml[rec * 2] = m_run;
-      p.ws_ml[rec * 2 + 1] = l_run;
+    if (through) {
+      if (nheads > 0) stage_half(std::integral_constant<int, 0>{});
+      if (tid == 0) flag[1] = (cell_seen >> 16) == p.epoch && (cell_seen & 0xffffu) == 1;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      other_in = flag[1] != 0;
+    }
+    if (!other_in) {
+      const int64_t rec0 = ((int64_t)row * p.H + head0) * p.nsplit + sp;
+      if (head_ok && h == 0) {
+        float* ml = p.ws_ml + (rec0 + (int64_t)c * p.nsplit) * 2;
+        if (through) {
+          const unsigned long long v = ((unsigned long long)__float_as_uint(l_run) << 32) | __float_as_uint(m_run);
+          __hip_atomic_store(reinterpret_cast<unsigned long long*>(ml), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          ml[0] = m_run;
+          ml[1] = l_run;
+        }
+      }
+      float* dst = p.ws_acc + rec0 * kR;
+      const int64_t pitch = (int64_t)p.nsplit * kR;
+      static_for<0, 2>([&](auto hc) __attribute__((always_inline)) {
+        if (nheads > 0 && !(through && decltype(hc)::value == 0)) stage_half(hc);
+#pragma unroll
+        for (int r = 0; r < 32; ++r)
+          if (r < nheads) {
+            float* at = dst + r * pitch + 256 * decltype(hc)::value;
+            if (through) store16_coherent(at, 16 * lane, staged_row(r));
+            else *reinterpret_cast<f32x4*>(at + 4 * lane) = staged_row(r);
+          }
+      });
     }
   }
-#pragma unroll
-  for (int db = 0; db < kDB; ++db)
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const f32x4 v = {o[db][4 * g4], o[db][4 * g4 + 1], o[db][4 * g4 + 2], o[db][4 * g4 + 3]};
-      *reinterpret_cast<f32x4*>(dst + 32 * db + 8 * g4) = v * inv;
+  WIDE_STAMP_END(1)
+  if (through) {
+    // The pair's records are written through the XCD's L2 and acknowledged before the workgroup is
+    // counted (device-scope fences instead -- a write-back and an invalidation of the whole L2 per
+    // wave -- measured 207 against 175 us with the merge kernel).  A cell counts while its upper 48
+    // bits are the launch's tag (decode_merge.h has the protocol: the workspace is never cleared);
+    // the second arriver resets it for a graph replay.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WIDE_STAMP_END(2)
+    __builtin_amdgcn_s_barrier();
+    if (tid == 0) {
+      unsigned long long* cell = p.counters + (int64_t)row * p.n_ht + ht;
+      unsigned long long seen = __hip_atomic_fetch_add(cell, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned long long next = seen + 1;
+      if ((seen >> 16) != p.epoch) {   // got here before split 0's mark, or the cell held something above every tag
+        seen = next;
+        do {
+          next = (seen >> 16) == p.epoch ? seen + 1 : ((p.epoch << 16) | 1ull);
+        } while (!__hip_atomic_compare_exchange_strong(cell, &seen, next, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT));
+      }
+      const int last = (int)(next & 0xffffu) == 2;
+      if (last) __hip_atomic_store(cell, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      flag[0] = last;
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const bool last = flag[0] != 0;
+    WIDE_STAMP_END(3)
+    if (last && nheads > 0) {
+      // out = (O_0 f_0 + O_1 f_1) / (l_0 f_0 + l_1 f_1) with the merge kernel's arithmetic, in split
+      // order whichever of the two is in registers.  Lane c works out head c's factors; the rows
+      // are combined in the staged layout (a row per instruction), whose factors come by readlane.
+      const int64_t rec_o = ((int64_t)row * p.H + head0) * 2 + (1 - sp);
+      const float* src = p.ws_acc + rec_o * kR;
+      float* dst = p.out + ((int64_t)row * p.H + head0) * kR + 4 * lane;
+      // The other record, half a row set (32 rows x 1 KiB) in flight at a time; this wave's own half
+      // is turned around in LDS, and the factors are worked out, while it travels.
+      f32x4 x[32];
+      auto fetch_half = [&](auto hc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 32; ++r) load16_coherent(x[r], src + (int64_t)min(r, nheads - 1) * (2 * kR) + 256 * decltype(hc)::value, 16 * lane);
+      };
+      auto await_half = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
+                       "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15])
+                     :
+                     : "memory");
+        asm volatile(""
+                     : "+v"(x[16]), "+v"(x[17]), "+v"(x[18]), "+v"(x[19]), "+v"(x[20]), "+v"(x[21]), "+v"(x[22]), "+v"(x[23]),
+                       "+v"(x[24]), "+v"(x[25]), "+v"(x[26]), "+v"(x[27]), "+v"(x[28]), "+v"(x[29]), "+v"(x[30]), "+v"(x[31])
+                     :
+                     : "memory");
+      };
+      fetch_half(std::integral_constant<int, 0>{});
+      float m_o = -1.0e30f, l_o = 0.f;
+      if (head_ok) {
+        const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p.ws_ml + (rec_o + 2 * c) * 2),
+                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        m_o = __uint_as_float((unsigned)v);
+        l_o = __uint_as_float((unsigned)(v >> 32));
+      }
+      if (!other_in) stage_half(std::integral_constant<int, 0>{});   // (else still there)
+      const float m0 = sp == 0 ? m_run : m_o, m1 = sp == 0 ? m_o : m_run;
+      const float l0 = sp == 0 ? l_run : l_o, l1 = sp == 0 ? l_o : l_run;
+      const float M = fmaxf(fmaxf(-1.0e30f, m0), m1);
+      const float f0 = fast_exp2(m0 - M), f1 = fast_exp2(m1 - M);
+      const float den = __builtin_fmaf(l1, f1, l0 * f0);
+      const float inv = den > 0.f ? 1.f / den : 0.f;
+      auto combine = [&](auto own_first) __attribute__((always_inline)) {
+        static_for<0, 2>([&](auto hc) __attribute__((always_inline)) {
+          constexpr int hf = decltype(hc)::value;
+          if constexpr (hf == 1) {
+            fetch_half(hc);
+            stage_half(hc);
+          }
+          await_half();
+#pragma unroll
+          for (int r = 0; r < 32; ++r) {
+            if (r < nheads) {
+              const f32x4 own = staged_row(r);
+              const float g0 = lane_value(f0, r), g1 = lane_value(f1, r), gi = lane_value(inv, r);
+              f32x4 res;
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                res[e] = (decltype(own_first)::value ? __builtin_fmaf(x[r][e], g1, own[e] * g0) : __builtin_fmaf(own[e], g1, x[r][e] * g0)) * gi;
+              *reinterpret_cast<f32x4*>(dst + (int64_t)r * kR + 256 * hf) = res;
+            }
+          }
+        });
+      };
+      if (sp == 0) combine(std::true_type{});
+      else combine(std::false_type{});
+    }
+  }
 #if WIDE_TIMING
+  __builtin_amdgcn_s_waitcnt(0);
+  WIDE_STAMP_END(4)
   if (blockIdx.x == 0 && tid == 0) {
-    __builtin_amdgcn_s_waitcnt(0);
     unsigned long long* t = reinterpret_cast<unsigned long long*>(p.out);
     t[0] = tm_bar;
     t[1] = tm_s;
     t[2] = tm_pv;
     t[3] = (unsigned long long)ntiles;
+  }
+  if (blockIdx.x < 8 && tid == 0) {   // the first workgroups' epilogues: (split, loop end, records issued, acknowledged, counted, done)
+    unsigned long long* t = reinterpret_cast<unsigned long long*>(p.out) + 8 + 8 * blockIdx.x;
+    t[0] = (unsigned long long)sp | ((unsigned long long)row << 8);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) t[1 + k] = te[k];
   }
 #endif
 }

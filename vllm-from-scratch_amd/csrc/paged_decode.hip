@@ -928,7 +928,6 @@ extern "C" size_t mi355_paged_decode_workspace_bytes(int32_t B, int32_t Hq, int3
 }
 
 namespace mi355 {
-namespace {
 
 // A 48-bit tag, different for every launch of this process and starting from a random value, by
 // which a launch tells its own arrival counts from whatever the workspace held before.  The top
@@ -940,6 +939,8 @@ unsigned long long next_launch_tag() {
   }()};
   return (counter.fetch_add(1, std::memory_order_relaxed) & ((1ull << 44) - 1)) | (0xFull << 44);
 }
+
+namespace {
 
 // The cache write of mi355_paged_decode_append as a launch of its own, for the shapes the
 // matrix-core decode kernel serves: thread = (sequence, kv head, 16-byte piece) stores that piece

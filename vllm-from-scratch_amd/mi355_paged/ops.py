@@ -436,15 +436,24 @@ def mla_fp32_supported(R: int, P: int) -> bool:
     return (R in (32, 64, 128) and P in (8, 16, 32, 64)) or (R in (256, 512) and P in (32, 64))
 
 
+def _mla_out(out: Optional[torch.Tensor], rows: int, H: int, R: int, dev: torch.device) -> torch.Tensor:
+    if out is None:
+        return torch.empty((rows, H, R), dtype=torch.float32, device=dev)
+    if out.dtype != torch.float32 or tuple(out.shape) != (rows, H, R) or not out.is_contiguous() or out.device != dev:
+        raise ValueError(f"out must be a contiguous fp32 [{rows}, {H}, {R}] tensor on {dev}")
+    return out
+
+
 def mla_decode(q: torch.Tensor, c_kv: torch.Tensor, k_rope: torch.Tensor, cos: torch.Tensor,
                sin: torch.Tensor, context_lens: torch.Tensor, max_context: int, scale: float,
-               row_seq: Optional[torch.Tensor] = None) -> torch.Tensor:
+               row_seq: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Latent-space MLA attention.
 
     q [rows, H, R + P] (absorbed nope query | rotated rope query); c_kv [S_seqs, S, R] and
     k_rope [S_seqs, S, P] (un-rotated) in q's dtype (bf16 / fp16, or fp32 where
     mla_fp32_supported(R, P)); cos / sin [table_len, P] fp32;
-    context_lens [rows] int32; row_seq [rows] int32 or None.  Returns [rows, H, R] fp32.
+    context_lens [rows] int32; row_seq [rows] int32 or None.  Returns [rows, H, R] fp32
+    (written into `out` when one is given: contiguous fp32 of that shape).
     """
     dev = require_device(q, c_kv, k_rope, cos, sin, context_lens, row_seq)
     lib = _lib.load()
@@ -478,7 +487,7 @@ def mla_decode(q: torch.Tensor, c_kv: torch.Tensor, k_rope: torch.Tensor, cos: t
     if int(max_context) > c_kv.shape[1] or int(max_context) > cos.shape[0]:
         raise ValueError(f"max_context {max_context} exceeds the cache rows ({c_kv.shape[1]}) or the "
                          f"cos/sin table ({cos.shape[0]})")
-    out = torch.empty((rows, H, R), dtype=torch.float32, device=dev)
+    out = _mla_out(out, rows, H, R, dev)
     code = dtype_code(q)
     with _on(dev):
         stream = _stream(dev)
@@ -498,7 +507,7 @@ def mla_decode(q: torch.Tensor, c_kv: torch.Tensor, k_rope: torch.Tensor, cos: t
 
 def mla_decode_paged(q: torch.Tensor, c_kv: torch.Tensor, k_rope: torch.Tensor, block_tables: torch.Tensor,
                      cos: torch.Tensor, sin: torch.Tensor, context_lens: torch.Tensor, max_context: int, scale: float,
-                     row_seq: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     row_seq: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Latent-space MLA attention over a block cache (mi355_mla_decode_paged).
 
     c_kv [blocks, block_size, R] and k_rope [blocks, block_size, P] -- typically the two column
@@ -540,7 +549,7 @@ def mla_decode_paged(q: torch.Tensor, c_kv: torch.Tensor, k_rope: torch.Tensor, 
     max_context = min(int(max_context), block_tables.shape[1] * block_size)
     if max_context > cos.shape[0]:
         raise ValueError(f"max_context {max_context} exceeds the cos/sin table ({cos.shape[0]})")
-    out = torch.empty((rows, H, R), dtype=torch.float32, device=dev)
+    out = _mla_out(out, rows, H, R, dev)
     code = dtype_code(q)
     with _on(dev):
         stream = _stream(dev)
