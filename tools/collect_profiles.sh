@@ -43,6 +43,8 @@ MASTER_ADDR=127.0.0.1 MASTER_PORT=29519 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 BENCH_F
 if [ -f tools/_ab/lib_wide_timing.so ]; then
   step phases of a step of the 128-heads-per-workgroup MLA kernel from the stamped side build
   MI355_PAGED_LIB=$PWD/tools/_ab/lib_wide_timing.so timeout -k 10 200 python3 tools/probe_wide_timeline.py > "$OUT/mla_wide_phases.txt" 2> "$OUT/mla_wide_phases.err"
+  echo "-- 128 rows: two token splits merged in the launch (split 0 shorter: it writes a record, split 1 combines)" >> "$OUT/mla_wide_phases.txt"
+  MI355_PAGED_LIB=$PWD/tools/_ab/lib_wide_timing.so timeout -k 10 200 python3 tools/probe_wide_timeline.py 128 128 4096 >> "$OUT/mla_wide_phases.txt" 2>> "$OUT/mla_wide_phases.err"
 fi
 if [ -f tools/_ab/lib_samp_t.so ]; then
   step sampler phases from the stamped side build

@@ -25,12 +25,25 @@ warm_card()
 for _ in range(20):
     out = ops.mla_decode(q, c, k, cos, sin, ctx, S, 0.072)
 torch.cuda.synchronize()
-t = out.view(-1)[:8].view(torch.int64).cpu().tolist()
-n = max(t[3], 1)
-print(f'steps {t[3]}: per step  barrier {t[0] / n:.0f}  score phase {t[1] / n:.0f}  value phase {t[2] / n:.0f}  total {(t[0] + t[1] + t[2]) / n:.0f} shader-clock ticks')
-t = out.view(-1)[:160].view(torch.int64).cpu().tolist()
-base = min(x for x in t[9:80:8] if x > 0)
-for b in range(8):     # the epilogues of workgroups 0 .. 7 on the 100 MHz clock, in microseconds from the earliest loop end
-    e = t[8 + 8 * b:16 + 8 * b]
-    print(f'workgroup {b}: row {e[0] >> 8} split {e[0] & 255}  loop end {(e[1] - base) / 100:.2f}  records issued +{(e[2] - e[1]) / 100:.2f}'
-          f'  acknowledged +{(e[3] - e[2]) / 100:.2f}  counted +{(e[4] - e[3]) / 100:.2f}  done +{(e[5] - e[4]) / 100:.2f} us')
+# Stamps at the end of the workspace, which a timing build makes 65 x 64 bytes larger: the epilogues of
+# workgroups 0 .. 63 on the 100 MHz clock, then workgroup 0's step phases on the shader clock.
+need = ops._lib.load().mi355_mla_decode_workspace_bytes(B, H, R, P, S, ops._DTYPE_CODE[torch.bfloat16])
+ws = ops._workspaces[(dev, torch.cuda.current_stream(dev).cuda_stream)]
+t = ws[need - 65 * 64:need].view(torch.int64).cpu().tolist()
+ph = t[8 * 64:]
+n = max(ph[3], 1)
+print(f'steps {ph[3]}: per step  barrier {ph[0] / n:.0f}  score phase {ph[1] / n:.0f}  value phase {ph[2] / n:.0f}  total {(ph[0] + ph[1] + ph[2]) / n:.0f} shader-clock ticks')
+rows = [t[8 * b:8 + 8 * b] for b in range(64)]
+base = min(e[1] for e in rows)
+shown = {}
+for e in rows:
+    split, row, other_in = e[0] & 255, (e[0] >> 8) & 0xffffffff, e[0] >> 40
+    if row >= 6:
+        continue
+    head = f'row {row} split {split} (XCD {e[7]}): started {(e[6] - base) / 100:7.2f}  loop end {(e[1] - base) / 100:6.2f}'
+    if e[3] == 0:      # wrote its rows (or its record for the merge kernel) and left
+        print(f'{head}  rows stored +{(e[2] - e[1]) / 100:.2f}  acknowledged +{(e[5] - e[2]) / 100:.2f} us')
+    else:
+        what = 'found the other counted, no record' if other_in else 'record issued'
+        print(f'{head}  {what} +{(e[2] - e[1]) / 100:.2f}  acknowledged +{(e[3] - e[2]) / 100:.2f}'
+              f'  counted +{(e[4] - e[3]) / 100:.2f}  {"combined and stored" if e[5] - e[4] > 100 else "left"} +{(e[5] - e[4]) / 100:.2f} us')

@@ -78,6 +78,7 @@ void mla_f32_plan(int rows, int H, int max_context, int* nsplit, int* tps, size_
 // rope 64, more than 64 heads, 16-bit dtypes.  `params` is the MlaParams block of mla_common.h.
 bool mla_wide_supported(int H, int R, int P, int dtype);
 int mla_wide_max_paged_tokens(int block_size);
+size_t mla_wide_stamp_bytes();
 int mla_wide_launch(const void* params, int dtype, bool paged, hipStream_t stream);
 // A 48-bit tag that differs for every launch of this process (paged_decode.hip): arrival cells in a
 // caller's workspace count only while they carry the launch's tag, so the workspace needs no clearing.

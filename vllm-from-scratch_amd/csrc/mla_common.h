@@ -39,6 +39,7 @@ struct MlaParams {
   // (row, head tile) behind the records, counting while it holds (epoch << 16); null: merge kernel.
   unsigned long long* counters = nullptr;
   unsigned long long epoch = 0;
+  unsigned long long* stamps = nullptr;   // timing side builds only: 65 x 8 clock stamps at the end of the workspace
 };
 
 // Addressing modes of the kernels below (template parameter PAGED).

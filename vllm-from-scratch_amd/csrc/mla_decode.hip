@@ -930,6 +930,7 @@ int mla_plan(int rows, int H, int R, int P, int max_context, int dtype, MlaPlan*
   // traffic and no second launch.  (R + 2 is even: the cells behind the records are 8-byte aligned.)
   pl.fused = pl.wide && pl.nsplit == 2 && knob(kKnobMlaWideFusedMerge) != 0;
   if (pl.fused) pl.ws_bytes += (size_t)rows * pl.n_ht * sizeof(unsigned long long);
+  if (pl.wide) pl.ws_bytes += mla_wide_stamp_bytes();   // (0 outside timing side builds)
   // Split 0 is given fewer tokens: its record is then in memory by the time split 1 is done, which
   // finds the pair's cell counted and combines without writing a record of its own.  All 256
   // workgroups writing records at once are bound by HBM (67 MB at 128 rows x 128 heads: 12 us).
@@ -953,12 +954,13 @@ int launch_tail(const MlaParams& p, hipStream_t s) {
   return 0;
 }
 
-int launch_wide_then_merge(MlaParams& p, int R, int dtype, bool paged, bool fused, int skew, hipStream_t s) {
+int launch_wide_then_merge(MlaParams& p, int R, int dtype, bool paged, bool fused, int skew, void* workspace, size_t ws_bytes, hipStream_t s) {
   if (fused) {
     p.tps -= skew;
     p.counters = reinterpret_cast<unsigned long long*>(p.ws_ml + (size_t)p.rows * p.H * p.nsplit * 2);
     p.epoch = next_launch_tag();
   }
+  if (mla_wide_stamp_bytes()) p.stamps = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + ws_bytes - mla_wide_stamp_bytes());
   if (int rc = mla_wide_launch(&p, dtype, paged, s)) return rc;
   if (p.counters) return 0;   // merged inside the launch
   return R == 512 ? launch_tail<512>(p, s) : fail(MI355_EUNSUPPORTED, "mla_decode: wide kernel at rank %d", R);
@@ -1143,11 +1145,11 @@ int mla_decode_impl(const char* what, float* out, const void* q, int64_t q_strid
     // 64-head kernel, with the same token splits and so the same workspace.
     if (pl.wide && scale > 0.f && p.tps + pl.skew < mla_wide_max_paged_tokens(pg.block_size) && ckv_stride_tok < (1 << 26) &&
         krope_stride_tok < (1 << 26))
-      return launch_wide_then_merge(p, R, dtype, true, pl.fused, pl.skew, s);
+      return launch_wide_then_merge(p, R, dtype, true, pl.fused, pl.skew, workspace, pl.ws_bytes, s);
     if (pl.wide) p.n_ht = (H + 4 * kHeadTile - 1) / (4 * kHeadTile);
     return dtype == MI355_BF16 ? launch_t<BF16, kPaged>(R, p, pl.many, s) : launch_t<F16, kPaged>(R, p, pl.many, s);
   }
-  if (pl.wide && scale > 0.f) return launch_wide_then_merge(p, R, dtype, false, pl.fused, pl.skew, s);
+  if (pl.wide && scale > 0.f) return launch_wide_then_merge(p, R, dtype, false, pl.fused, pl.skew, workspace, pl.ws_bytes, s);
   if (pl.wide) p.n_ht = (H + 4 * kHeadTile - 1) / (4 * kHeadTile);
   return dtype == MI355_BF16 ? launch_t<BF16, kDense>(R, p, pl.many, s) : launch_t<F16, kDense>(R, p, pl.many, s);
 }

@@ -419,7 +419,8 @@ __global__ void __launch_bounds__(256) MI355_NO_PACKED_F32 mla_decode_kernel_wid
 #define WIDE_STAMP(acc)
 #endif
 #if WIDE_TIMING
-  unsigned long long te[6] = {};   // the epilogue's phases on the 100 MHz clock
+  unsigned long long te[6] = {};   // the epilogue's phases on the 100 MHz clock ([5]: when the workgroup started)
+  te[5] = __builtin_amdgcn_s_memrealtime();
 #define WIDE_STAMP_END(k) te[k] = __builtin_amdgcn_s_memrealtime();
 #else
 #define WIDE_STAMP_END(k)
@@ -689,7 +690,12 @@ __global__ void __launch_bounds__(256) MI355_NO_PACKED_F32 mla_decode_kernel_wid
   } else {
     if (through) {
       if (nheads > 0) stage_half(std::integral_constant<int, 0>{});
-      if (tid == 0) flag[1] = (cell_seen >> 16) == p.epoch && (cell_seen & 0xffffu) == 1;
+      if (tid == 0) {
+        // (asking again for a bounded while when split 0 is not in yet -- up to 32 times, ~0.7 us
+        // each -- measured no gain: 163.3 against 163.9 us)
+        const unsigned long long counted_once = (p.epoch << 16) | 1ull;   // the launch's tag, one arrival
+        flag[1] = cell_seen == counted_once;
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       other_in = flag[1] != 0;
@@ -723,8 +729,8 @@ __global__ void __launch_bounds__(256) MI355_NO_PACKED_F32 mla_decode_kernel_wid
   WIDE_STAMP_END(1)
   if (through) {
     // The pair's records are written through the XCD's L2 and acknowledged before the workgroup is
-    // counted (device-scope fences instead -- a write-back and an invalidation of the whole L2 per
-    // wave -- measured 207 against 175 us with the merge kernel).  A cell counts while its upper 48
+    // counted (plain accesses between a device-scope release and acquire instead -- a write-back and
+    // an invalidation of the whole L2 per wave -- measured 195-200 against 166-170 us).  A cell counts while its upper 48
     // bits are the launch's tag (decode_merge.h has the protocol: the workspace is never cleared);
     // the second arriver resets it for a graph replay.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -820,18 +826,22 @@ __global__ void __launch_bounds__(256) MI355_NO_PACKED_F32 mla_decode_kernel_wid
 #if WIDE_TIMING
   __builtin_amdgcn_s_waitcnt(0);
   WIDE_STAMP_END(4)
-  if (blockIdx.x == 0 && tid == 0) {
-    unsigned long long* t = reinterpret_cast<unsigned long long*>(p.out);
+  if (blockIdx.x == 0 && tid == 0 && p.stamps) {
+    unsigned long long* t = p.stamps + 8 * 64;
     t[0] = tm_bar;
     t[1] = tm_s;
     t[2] = tm_pv;
     t[3] = (unsigned long long)ntiles;
   }
-  if (blockIdx.x < 8 && tid == 0) {   // the first workgroups' epilogues: (split, loop end, records issued, acknowledged, counted, done)
-    unsigned long long* t = reinterpret_cast<unsigned long long*>(p.out) + 8 + 8 * blockIdx.x;
-    t[0] = (unsigned long long)sp | ((unsigned long long)row << 8);
+  if (blockIdx.x < 64 && tid == 0 && p.stamps) {   // the first workgroups' epilogues: (split, loop end, records issued, acknowledged, counted, done)
+    unsigned long long* t = p.stamps + 8 * blockIdx.x;
+    t[0] = (unsigned long long)sp | ((unsigned long long)row << 8) | ((unsigned long long)other_in << 40);
 #pragma unroll
     for (int k = 0; k < 5; ++k) t[1 + k] = te[k];
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    t[6] = te[5];
+    t[7] = xcc & 15;
   }
 #endif
 }
@@ -854,6 +864,9 @@ int launch_wide(const MlaParams& p, hipStream_t s) {
 }
 
 }  // namespace
+
+// Bytes a -DWIDE_TIMING=1 side build appends to the workspace for its epilogue stamps (else 0).
+size_t mla_wide_stamp_bytes() { return WIDE_TIMING ? 65 * 8 * sizeof(unsigned long long) : 0; }
 
 bool mla_wide_supported(int H, int R, int P, int dtype) {
   const int least = knob(kKnobMlaWide);   // 0: off
