@@ -578,7 +578,7 @@ def test_wide_kernel_scores_that_keep_growing(ops, device):
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('shape', [(2, 128, 700, 16), (1, 100, 3000, 64), (3, 128, 130, 1), (2, 72, 1500, 8), (2, 128, 333, 128),
-                                   (1, 128, 2500, 1)])
+                                   (1, 128, 2500, 1), (2, 32, 900, 16), (3, 48, 1500, 8), (2, 20, 260, 32)])
 def test_wide_kernel_paged_equals_dense(ops, device, shape, dtype):
     """The 128-heads-per-workgroup kernel over a block cache: the dense call's result bit for bit,
     for block sizes 1 .. 128 (ids staged in LDS per workgroup; a token range with more blocks than fit
@@ -619,7 +619,7 @@ def _where_unequal(got, want):
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('shape', [(3, 128, 2100, 6, 0), (5, 40, 700, 10, 0), (2, 200, 1300, 8, 0), (4, 128, 4096, 8, 16),
-                                   (128, 128, 2300, 0, 0)])
+                                   (128, 128, 2300, 0, 0), (4, 24, 1300, 8, 0), (3, 31, 2100, 6, 16), (6, 64, 1100, 12, 0)])
 def test_wide_kernel_merges_two_token_splits_in_the_launch(ops, device, shape, dtype):
     """Two token splits of the 128-heads-per-workgroup kernel: the workgroup of a pair that finishes
     later combines its registers with the other's record (MI355_MLA_WIDE_FUSED_MERGE, the default) --
