@@ -699,3 +699,34 @@ def test_wide_kernel_merges_two_token_splits_in_the_launch(ops, device, shape, d
             with ops.debug_knob('MI355_MLA_WIDE_FUSED_MERGE', 0):
                 want = call(q, ctx)
             assert torch.equal(out.view(torch.int32), want.view(torch.int32)), f"replay {it}"
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('shape', [(1, 128, 20000), (3, 16, 30000), (2, 64, 9000)])
+def test_many_splits_of_few_rows_match_the_oracle(ops, device, shape, dtype):
+    """Few rows with long contexts run as hundreds of token splits, combined by the kernel that spreads a
+    row's splits over the threads of a workgroup: against the oracle on a sample of heads, with a full
+    row, a row that fills only some of the splits, and an empty one."""
+    rows, H, S = shape
+    R, P = 512, 64
+    if dtype == torch.float32 and not ops.mla_fp32_supported(R, P):
+        pytest.skip("no fp32 kernel for this rank")
+    rng = np.random.default_rng(rows + H + S)
+    q = torch.from_numpy(rng.standard_normal((rows, H, R + P), dtype=np.float32) * 0.3).to(dtype)
+    c_kv = torch.from_numpy(rng.standard_normal((1, S, R), dtype=np.float32)).to(dtype)
+    k_rope = torch.from_numpy(rng.standard_normal((1, S, P), dtype=np.float32)).to(dtype)
+    ctx = np.array(([S, S // 7, 0] * rows)[:rows], dtype=np.int32)
+    row_seq = torch.zeros((rows,), dtype=torch.int32, device=device)
+    cos, sin = mo.rope_tables(P, S)
+    code = ops._DTYPE_CODE[dtype]
+    assert ops._lib.load().mi355_mla_decode_workspace_bytes(rows, H, R, P, S, code) >= rows * H * 8 * (R + 2) * 4, \
+        "the case is meant to run at least eight splits"
+    out = ops.mla_decode(q.to(device), c_kv.to(device), k_rope.to(device), torch.from_numpy(cos).to(device),
+                         torch.from_numpy(sin).to(device), torch.from_numpy(ctx).to(device), S, 0.06,
+                         row_seq=row_seq).cpu().numpy()
+    heads = sorted({0, H // 2, H - 1})
+    want = mo.latent_attention(q[:, heads].float().numpy(), np.repeat(c_kv.float().numpy(), rows, 0),
+                               np.repeat(k_rope.float().numpy(), rows, 0), cos, sin, ctx, 0.06)
+    tol = dict(rtol=2e-4, atol=2e-5) if dtype == torch.float32 else TOL[dtype]
+    np.testing.assert_allclose(out[:, heads], want, **tol)
+    assert not out[ctx == 0].any()

@@ -864,6 +864,86 @@ __global__ void __launch_bounds__(256) mla_merge_kernel(const MlaParams p) {
   *reinterpret_cast<f32x4*>(p.out + rh * R + dv * 4) = acc * inv;
 }
 
+// The same combination for many splits of few rows (one long sequence spread over the chip): the
+// kernel above gives a thread all the splits of its four dims, one after the other -- 16 384 threads
+// walking 256 records each took 43 of the 77 us of 1 row x 128 heads x 32 768 tokens.  Here a
+// workgroup owns (row, head, 128 dims) and its eight groups of 32 lanes each take every eighth
+// split; the groups' sums meet in LDS in a fixed order.  Factors exp2(m_s - M) are worked out once per
+// workgroup and kept in LDS (up to kMergeManyCap splits).
+constexpr int kMergeManyCap = 2048;
+constexpr int kMergeManyMin = 8;     // fewer splits: the kernel above
+
+template <int R>
+__global__ void __launch_bounds__(256) mla_merge_many_kernel(const MlaParams p) {
+  constexpr int kChunks = R / 128;
+  __shared__ float s_f[kMergeManyCap];
+  __shared__ float s_wave[2][4];
+  __shared__ f32x4 s_acc[8][32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int dvl = tid & 31, grp = tid >> 5;
+  const int chunk = (int)(blockIdx.x % kChunks);
+  const int64_t rh = blockIdx.x / kChunks;
+  const int row = (int)(rh / p.H);
+  const int ctx = max(0, min(p.ctx[row], p.max_ctx));
+  const int nvalid = min(p.nsplit, (ctx + p.tps - 1) / p.tps);
+  const float* ml = p.ws_ml + rh * p.nsplit * 2;
+  float m = -1.0e30f;
+  for (int s = tid; s < nvalid; s += 256) m = fmaxf(m, ml[2 * s]);
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if (lane == 0) s_wave[0][wave] = m;
+  __syncthreads();
+  const float M = fmaxf(fmaxf(s_wave[0][0], s_wave[0][1]), fmaxf(s_wave[0][2], s_wave[0][3]));
+  float d = 0.f;
+  for (int s = tid; s < nvalid; s += 256) {
+    const float f = fast_exp2(ml[2 * s] - M);
+    s_f[s] = f;
+    d = __builtin_fmaf(ml[2 * s + 1], f, d);
+  }
+  d = group_sum<64>(d);
+  if (lane == 0) s_wave[1][wave] = d;
+  __syncthreads();
+  const float den = (s_wave[1][0] + s_wave[1][1]) + (s_wave[1][2] + s_wave[1][3]);
+  const float* pa = p.ws_acc + rh * p.nsplit * R + chunk * 128 + dvl * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  int s = grp;
+  for (; s + 24 < nvalid; s += 32) {      // four records in flight per thread
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(pa + (size_t)s * R);
+    const f32x4 a1 = *reinterpret_cast<const f32x4*>(pa + (size_t)(s + 8) * R);
+    const f32x4 a2 = *reinterpret_cast<const f32x4*>(pa + (size_t)(s + 16) * R);
+    const f32x4 a3 = *reinterpret_cast<const f32x4*>(pa + (size_t)(s + 24) * R);
+    acc += a0 * s_f[s];
+    acc += a1 * s_f[s + 8];
+    acc += a2 * s_f[s + 16];
+    acc += a3 * s_f[s + 24];
+  }
+  for (; s < nvalid; s += 8) acc += *reinterpret_cast<const f32x4*>(pa + (size_t)s * R) * s_f[s];
+  s_acc[grp][dvl] = acc;
+  __syncthreads();
+  if (grp == 0) {
+    f32x4 total = s_acc[0][dvl];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) total += s_acc[g][dvl];
+    const float inv = den > 0.f ? 1.f / den : 0.f;
+    *reinterpret_cast<f32x4*>(p.out + rh * R + chunk * 128 + dvl * 4) = total * inv;
+  }
+}
+
+// Launches the combination of a launch's split records on `s`.
+template <int R>
+void launch_merge(const MlaParams& p, hipStream_t s) {
+  if constexpr (R >= 128) {
+    // (from about 512 workgroups of the kernel above on, its threads are enough to keep memory busy
+    // and its single pass is faster: 32 rows x 128 heads x 8 splits 70.0 against 75.0 us)
+    if (p.nsplit >= kMergeManyMin && p.nsplit <= kMergeManyCap && (int64_t)p.rows * p.H * (R / 4) <= 512 * 256) {
+      hipLaunchKernelGGL((mla_merge_many_kernel<R>), dim3((unsigned)((int64_t)p.rows * p.H * (R / 128))), dim3(256), 0, s, p);
+      return;
+    }
+  }
+  const int64_t threads = (int64_t)p.rows * p.H * (R / 4);
+  hipLaunchKernelGGL((mla_merge_kernel<R>), dim3((unsigned)ceil_div64(threads, 256)), dim3(256), 0, s, p);
+}
+
 struct MlaPlan {
   bool many;
   bool wide;   // 128 heads per workgroup (mla_decode_wide.hip)
@@ -947,8 +1027,7 @@ template <int R>
 int launch_tail(const MlaParams& p, hipStream_t s) {
   if (int rc = check_launch("mla_decode_kernel")) return rc;
   if (p.nsplit > 1) {
-    const int64_t threads = (int64_t)p.rows * p.H * (R / 4);
-    hipLaunchKernelGGL((mla_merge_kernel<R>), dim3((unsigned)ceil_div64(threads, 256)), dim3(256), 0, s, p);
+    launch_merge<R>(p, s);
     return check_launch("mla_merge_kernel");
   }
   return 0;
@@ -1016,14 +1095,12 @@ int mla_merge_launch(float* out, float* ws_acc, float* ws_ml, const int32_t* ctx
   p.max_ctx = max_ctx;
   p.nsplit = nsplit;
   p.tps = tps;
-  const int64_t threads = (int64_t)rows * H * (R / 4);
-  const dim3 grid((unsigned)ceil_div64(threads, 256));
   switch (R) {
-    case 32: hipLaunchKernelGGL((mla_merge_kernel<32>), grid, dim3(256), 0, stream, p); break;
-    case 64: hipLaunchKernelGGL((mla_merge_kernel<64>), grid, dim3(256), 0, stream, p); break;
-    case 128: hipLaunchKernelGGL((mla_merge_kernel<128>), grid, dim3(256), 0, stream, p); break;
-    case 256: hipLaunchKernelGGL((mla_merge_kernel<256>), grid, dim3(256), 0, stream, p); break;
-    case 512: hipLaunchKernelGGL((mla_merge_kernel<512>), grid, dim3(256), 0, stream, p); break;
+    case 32: launch_merge<32>(p, stream); break;
+    case 64: launch_merge<64>(p, stream); break;
+    case 128: launch_merge<128>(p, stream); break;
+    case 256: launch_merge<256>(p, stream); break;
+    case 512: launch_merge<512>(p, stream); break;
     default: return fail(MI355_EUNSUPPORTED, "mla merge: kv_lora_rank %d", R);
   }
   return check_launch("mla_merge_kernel");
