@@ -702,13 +702,13 @@ def test_wide_kernel_merges_two_token_splits_in_the_launch(ops, device, shape, d
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
-@pytest.mark.parametrize('shape', [(1, 128, 20000), (3, 16, 30000), (2, 64, 9000)])
+@pytest.mark.parametrize('shape', [(1, 128, 20000), (3, 16, 30000), (2, 64, 9000), (2, 16, 12000, 128, 64), (1, 32, 9000, 256, 32)])
 def test_many_splits_of_few_rows_match_the_oracle(ops, device, shape, dtype):
     """Few rows with long contexts run as hundreds of token splits, combined by the kernel that spreads a
     row's splits over the threads of a workgroup: against the oracle on a sample of heads, with a full
     row, a row that fills only some of the splits, and an empty one."""
-    rows, H, S = shape
-    R, P = 512, 64
+    rows, H, S = shape[:3]
+    R, P = shape[3:] if len(shape) > 3 else (512, 64)
     if dtype == torch.float32 and not ops.mla_fp32_supported(R, P):
         pytest.skip("no fp32 kernel for this rank")
     rng = np.random.default_rng(rows + H + S)
